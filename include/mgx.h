@@ -1,0 +1,225 @@
+/*
+ * mgx.h — C-ABI of libmgx: MI355X-native geometric multigrid for the 2-D
+ * Poisson problem, the drop-in for the hot path of nikhilTkur/Multigrid_Nikhil_C-.
+ *
+ * The reference exposes no FFI: its interface is a set of C++ free functions
+ * in one translation unit called from main().  Each entry point
+ * below names the reference function or block it replaces
+ * (PS = Poissons_SYCL.cpp, MF = Multigrid_functions.cpp).  A header-only C++
+ * wrapper with the reference's own names and std::vector signatures is in
+ * include/mgx_reference_api.hpp; INTEGRATION.md shows the binding a maintainer
+ * would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types, never throws.
+ *   - every function returns an mgx_status (0 = ok); mgx_last_error() gives text.
+ *   - host vectors use the reference's layout: interior-only, row-major,
+ *     n x n with n = 2^L - 1 (PS:227-233, PS:291, PS:662-664); element type is
+ *     double for dtype F64 and MIXED, float for dtype F32.
+ *   - device memory is owned by the handle; one host thread per handle; calls
+ *     block until the result is available unless the name ends in _async.
+ *   - there is no CPU fallback: creation fails with MGX_ERR_NO_DEVICE when no
+ *     gfx950 device is usable.
+ */
+#ifndef MGX_H
+#define MGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGX_API __attribute__((visibility("default")))
+
+typedef enum {
+    MGX_OK = 0,
+    MGX_ERR_INVALID = 1,      /* bad argument / configuration */
+    MGX_ERR_NO_DEVICE = 2,    /* no usable HIP device */
+    MGX_ERR_HIP = 3,          /* a HIP runtime call failed */
+    MGX_ERR_ALLOC = 4,
+    MGX_ERR_STATE = 5         /* call not valid in the handle's current state */
+} mgx_status;
+
+enum { MGX_SMOOTHER_JACOBI = 0, MGX_SMOOTHER_RBGS = 1 };
+enum { MGX_DTYPE_F32 = 0, MGX_DTYPE_F64 = 1, MGX_DTYPE_MIXED = 2 };
+enum { MGX_SCHEDULE_V = 0, MGX_SCHEDULE_FMG = 1 };
+enum { MGX_RESTRICT_CONSISTENT = 0, MGX_RESTRICT_FW16 = 1 };
+enum { MGX_BOTTOM_EXACT = 0, MGX_BOTTOM_SMOOTH = 1 };
+
+/* The reference's compile-time globals as run-time fields.
+ * PS:17-22 (finest_level, coarsest_level, mu0, mu1, mu2), PS:127 (omega);
+ * MF:43-48 holds the draft's values of the same names. */
+typedef struct {
+    int finest_level;     /* PS:17  */
+    int coarsest_level;   /* PS:18  */
+    int mu0;              /* PS:20  FMG runs mu0+1 V-cycles per level (PS:646) */
+    int mu1;              /* PS:21  pre-smoothing sweeps  */
+    int mu2;              /* PS:22  post-smoothing sweeps */
+    double omega;         /* PS:127 Jacobi weight */
+    int smoother;         /* MGX_SMOOTHER_*  (RBGS: BASELINE config 3) */
+    int dtype;            /* MGX_DTYPE_*     (PS is f32, MF is f64; MIXED: config 5) */
+    int schedule;         /* MGX_SCHEDULE_*  (PS:727 calls fullmultigrid = FMG) */
+    int restrict_mode;    /* MGX_RESTRICT_*   */
+    int bottom;           /* MGX_BOTTOM_*    (EXACT: MF:137-139; SMOOTH: PS:581-587, D8) */
+    int device;           /* HIP device ordinal */
+    int profile;          /* 1: record HIP events around each operator class */
+} mgx_config;
+
+typedef struct mgx_solver* mgx_handle;
+
+/* Fills the reference's defaults (PS:17-22, 127): levels 10..7, mu 30/10/10,
+ * omega 2/3, Jacobi, FMG; dtype F64, consistent restriction, exact bottom. */
+MGX_API int mgx_config_default(mgx_config* cfg);
+
+/* Grid-hierarchy constructor: replaces the per-level loop of main()
+ * (PS:661-690: globalstiffenssmatrix + coo_to_csr + init_matrix_handle +
+ * set_csr_data filling jacobi_matrices[level - coarsest_level], PS:33).
+ * Matrix-free: allocates per-level device arrays instead of CSR handles. */
+MGX_API int mgx_create(const mgx_config* cfg, mgx_handle* out);
+MGX_API int mgx_destroy(mgx_handle h);
+MGX_API const char* mgx_last_error(mgx_handle h);   /* h may be NULL: last create error */
+MGX_API const char* mgx_status_string(int status);
+
+/* Interior points per side at `level`, n = 2^level - 1 (PS:662-664). */
+MGX_API int mgx_level_n(int level);
+
+/* ---- data in / out (host buffers, reference layout) ---------------------- */
+/* which: vector selector for level-wise access */
+enum { MGX_VEC_U = 0, MGX_VEC_B = 1, MGX_VEC_R = 2 };
+
+/* Right-hand side of the finest level: replaces globalforcefunction()'s
+ * output handed to fullmultigrid (PS:725-727).  count must be n*n. */
+MGX_API int mgx_set_rhs(mgx_handle h, const void* b, size_t count);
+/* Initial guess / result of the finest level (PS:630 starts from zero). */
+MGX_API int mgx_set_guess(mgx_handle h, const void* u, size_t count);
+MGX_API int mgx_get_solution(mgx_handle h, void* u, size_t count);
+/* Level-wise access for operator tests.  Element type: the level's working
+ * type (float for F32; double for F64; for MIXED the finest-level U/B/R are
+ * double and everything else float). */
+MGX_API int mgx_set_level(mgx_handle h, int level, int which, const void* src, size_t count);
+MGX_API int mgx_get_level(mgx_handle h, int level, int which, void* dst, size_t count);
+/* Built-in right-hand sides, generated on the device:
+ * kind 0: b = f h^2, the reference's load vector (PS:283-335, f = 4 at PS:123)
+ * kind 1: b = h^2 8 pi^2 sin(2 pi x) sin(2 pi y)   (`f` ignored). */
+MGX_API int mgx_fill_rhs(mgx_handle h, int kind, double f);
+/* u ~ U(-1,1) from a counter-based generator keyed on (seed, index). */
+MGX_API int mgx_fill_guess_random(mgx_handle h, uint64_t seed);
+
+/* ---- grid operators (one call = the reference function named) ------------ */
+/* jacobirelaxation(q, a_lu, size, v, f, mu)  PS:125-147 / MF:75-96; with
+ * smoother = RBGS: mu red-black Gauss-Seidel sweeps.  Acts on U,B of `level`. */
+MGX_API int mgx_smooth(mgx_handle h, int level, int mu);
+/* residual block of vcyclemultigrid  PS:591-608 / MF:145-153:  R = B - A U. */
+MGX_API int mgx_residual(mgx_handle h, int level);
+/* restriction2d(residual)  PS:531-546, 611:  B[level-1] = R(B[level] - A U[level]),
+ * residual fused in; also zeroes U[level-1] (PS:613). */
+MGX_API int mgx_restrict(mgx_handle h, int level);
+/* restriction2d(f_h)  PS:641: B[level-1] = R(B[level])  (FMG right-hand sides). */
+MGX_API int mgx_restrict_rhs(mgx_handle h, int level);
+/* interpolation2d + vm::add  PS:620-624:  U[level] += P U[level-1]. */
+MGX_API int mgx_prolong_add(mgx_handle h, int level);
+/* interpolation2d  PS:337-425, 645:  U[level] = P U[level-1]. */
+MGX_API int mgx_prolong(mgx_handle h, int level);
+/* coarsest-level solve U = A^-1 B  (MF:63-72 direct_solver, MF:137-139). */
+MGX_API int mgx_bottom_solve(mgx_handle h);
+/* ||B - A U||_2 on `level` (the report D10 says the reference lacks). */
+MGX_API int mgx_residual_norm(mgx_handle h, int level, double* out);
+
+/* ---- schedules ------------------------------------------------------------- */
+/* vcyclemultigrid(q, a_h, vec_h, f_h) from `level` down  PS:575-627 / MF:132-173 */
+MGX_API int mgx_vcycle(mgx_handle h, int level);
+/* fullmultigrid(q, a_h, f_h)  PS:629-650 / MF:175-191 on the finest level. */
+MGX_API int mgx_fmg(mgx_handle h);
+
+typedef struct {
+    int cycles;                 /* cycles run (an FMG pass counts as cycle 1) */
+    int converged;              /* 1 if ||r|| <= tol ||r0|| */
+    double initial_residual;    /* ||b - A u0||_2 */
+    double final_residual;
+    double seconds;             /* wall time of the solve, device-synchronised */
+    double fine_updates;        /* finest-level smoother point updates performed */
+    int history_len;            /* entries written to `history` (cycles + 1) */
+} mgx_stats;
+
+/* main()'s call `fullmultigrid(q, jacobi_matrices.back(), f_global)` PS:727 /
+ * multigrid_solver(ProblemVar&) MF:193-197, run to a tolerance: cycles until
+ * ||r||_2 <= tol ||r0||_2 or max_cycles.  history (may be NULL) receives
+ * ||r||_2 before the first cycle and after each one; capacity history_cap. */
+MGX_API int mgx_solve(mgx_handle h, double tol, int max_cycles, mgx_stats* stats,
+                      double* history, int history_cap);
+
+/* ---- measurement ------------------------------------------------------------ */
+enum {
+    MGX_PROF_SMOOTH_FINE = 0,   /* finest-level smoother launches */
+    MGX_PROF_RESTRICT_FINE = 1, /* finest-level fused residual+restriction */
+    MGX_PROF_PROLONG_FINE = 2,  /* finest-level prolongation+correction */
+    MGX_PROF_NORM_FINE = 3,     /* finest-level residual norm */
+    MGX_PROF_COARSE = 4,        /* everything below the finest level */
+    MGX_PROF_COUNT = 5
+};
+typedef struct {
+    double ms[MGX_PROF_COUNT];        /* accumulated HIP-event time */
+    long long launches[MGX_PROF_COUNT]; /* kernel launches inside those intervals */
+} mgx_profile;
+/* Valid when cfg.profile = 1; events are recorded on the handle's stream. */
+MGX_API int mgx_profile_reset(mgx_handle h);
+MGX_API int mgx_profile_get(mgx_handle h, mgx_profile* out);
+/* `sweeps` finest-level smoother sweeps bracketed by HIP events on the
+ * handle's stream; returns the elapsed milliseconds. */
+MGX_API int mgx_time_smoother(mgx_handle h, int sweeps, double* ms);
+MGX_API int mgx_synchronize(mgx_handle h);
+
+/* =============================================================================
+ * Slab-level operators on caller-owned device memory.  These are what the
+ * multi-GPU driver (one process per GPU, RCCL halo exchange between calls)
+ * composes; the single-GPU handle above uses the same kernels.
+ *
+ * A slab is `rows` consecutive grid rows of one level stored with the level's
+ * pitch (mgx_level_pitch), columns 0..N as in the handle (Dirichlet columns
+ * and padding must be zero).  Row indices are local to the slab.  `stream` is
+ * a hipStream_t passed as void* (NULL = default stream).  dtype is
+ * MGX_DTYPE_F32 or MGX_DTYPE_F64.  Calls are asynchronous on `stream`.
+ * ===========================================================================*/
+typedef struct {
+    int level;        /* grid level L: N = 2^L, columns 0..N */
+    int dtype;        /* MGX_DTYPE_F32 / MGX_DTYPE_F64 */
+    int rows;         /* rows allocated in the slab */
+    int row0;         /* global row index of local row 0 */
+} mgx_slab;
+
+/* elements per row for (level, dtype); bytes per row = pitch * sizeof(type) */
+MGX_API long mgx_level_pitch(int level, int dtype);
+
+/* mu Jacobi sweeps (PS:125-147) on local rows [row_lo,row_hi), ping-ponging
+ * u <-> tmp; with shrink = 1 the range shrinks by one row per sweep at each
+ * end that is not a global boundary (deep-halo communication avoidance): the
+ * first sweep then covers [row_lo - (mu-1), row_hi + (mu-1)) clipped to the
+ * unknown rows.  *result_in_tmp is set to 1 when mu is odd. */
+MGX_API int mgx_slab_jacobi(const mgx_slab* s, void* u, const void* b, void* tmp,
+                            int row_lo, int row_hi, int mu, double omega, int shrink,
+                            int* result_in_tmp, void* stream);
+/* same for red-black Gauss-Seidel; a sweep consumes two halo rows per side */
+MGX_API int mgx_slab_rbgs(const mgx_slab* s, void* u, const void* b, void* tmp,
+                          int row_lo, int row_hi, int mu, int shrink,
+                          int* result_in_tmp, void* stream);
+/* fused residual + restriction (PS:604-611) of fine slab `f` into coarse slab
+ * `c`, coarse local rows [crow_lo,crow_hi); zero_u (may be NULL) is the coarse
+ * solution slab to zero on the same rows (PS:613). */
+MGX_API int mgx_slab_restrict(const mgx_slab* f, const void* u, const void* b,
+                              const mgx_slab* c, void* cb, void* zero_u,
+                              int crow_lo, int crow_hi, int restrict_mode, int fused, void* stream);
+/* u[fine rows row_lo..row_hi) (+)= P e  (PS:337-425, 620-624) */
+MGX_API int mgx_slab_prolong(const mgx_slab* f, void* u, const mgx_slab* c, const void* e,
+                             int row_lo, int row_hi, int add, void* stream);
+/* sum over rows [row_lo,row_hi) of (b - A u)^2 -> *partial_sum_dev (device
+ * double, written asynchronously); scratch must hold mgx_slab_scratch_doubles(). */
+MGX_API int mgx_slab_residual_sumsq(const mgx_slab* s, const void* u, const void* b,
+                                    int row_lo, int row_hi, double* scratch, double* sum_dev, void* stream);
+MGX_API long mgx_slab_scratch_doubles(const mgx_slab* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H */

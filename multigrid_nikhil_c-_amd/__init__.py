@@ -1,0 +1,14 @@
+"""mgx — MI355X-native geometric multigrid for the 2-D Poisson problem.
+
+Drop-in for the hot path of nikhilTkur/Multigrid_Nikhil_C- (smoother, residual,
+restriction, prolongation, V-cycle / FMG schedules).  The product
+is libmgx.so (C-ABI: include/mgx.h) built from csrc/; this package is the thin
+ctypes view of it plus the multi-GPU slab driver.  The directory name carries
+the reference's name, so import it through __graft_entry__.load_package()
+(registered as `multigrid_nikhil_c_amd`).
+"""
+from .binding import (  # noqa: F401
+    BOTTOM_EXACT, BOTTOM_SMOOTH, DTYPE_F32, DTYPE_F64, DTYPE_MIXED, EXPORTS, LIB_PATH,
+    RESTRICT_CONSISTENT, RESTRICT_FW16, SCHEDULE_FMG, SCHEDULE_V, SMOOTHER_JACOBI,
+    SMOOTHER_RBGS, VEC_B, VEC_R, VEC_U, Config, MgxError, Multigrid, Slab, default_config, lib,
+)

@@ -1,0 +1,993 @@
+// mgx.hip — libmgx: solver handle, V-cycle / FMG schedules and the C-ABI
+// (include/mgx.h) over the gfx950 kernels of mgx_kernels.hpp.
+//
+// Reference map (PS = Poissons_SYCL.cpp, MF = Multigrid_functions.cpp):
+//   Solver / Level      PS:24-33 matrix_elements_for_jacobi + jacobi_matrices[],
+//                       MF:16-26 ProblemVar   (matrix-free: arrays, no CSR)
+//   Solver::vcycle      PS:575-627 vcyclemultigrid / MF:132-173
+//   Solver::fmg         PS:629-650 fullmultigrid   / MF:175-191
+//   mgx_solve           PS:727 (main's call) / MF:193-197 multigrid_solver
+// There is no CPU fallback anywhere in this file.
+
+#include "../../include/mgx.h"
+#include "mgx_bottom.hpp"
+#include "mgx_kernels.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+using namespace mgx;
+
+thread_local std::string g_create_error;
+
+inline long level_pitch(int level, int dtype)
+{
+    const long N = 1L << level;
+    const long align = (dtype == MGX_DTYPE_F64) ? 32 : 64;   // 256 bytes
+    return (N + 1 + align - 1) / align * align;
+}
+
+inline int env_int(const char* name, int dflt)
+{
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+struct Level {
+    int L = 0, N = 0, rows = 0;
+    long pitch = 0;
+    size_t bytes = 0;
+    bool f64 = true;
+    void *u = nullptr, *b = nullptr, *tmp = nullptr, *r = nullptr;
+    size_t esize() const { return f64 ? 8 : 4; }
+};
+
+struct EventPair { hipEvent_t a, b; int cls; long long launches; };
+
+} // namespace
+
+struct mgx_solver {
+    mgx_config cfg{};
+    hipStream_t stream = nullptr;
+    std::vector<Level> lv;          // working hierarchy, index = level (only [coarsest..finest] valid)
+    Level fine64;                   // MIXED only: double u, b (and r) on the finest level
+    bool mixed = false;
+    bool work_f64 = true;           // element type of the working hierarchy
+    BottomDST bottom;
+    double* partial = nullptr;      // per-block partial sums
+    long partial_cap = 0;
+    double* sum_dev = nullptr;      // reduced sum (device)
+    double* sum_host = nullptr;     // pinned
+    std::string err;
+    int rows_per_chunk = 0;         // 0 = auto (MGX_ROWS env overrides)
+    // profiling
+    std::vector<EventPair> ev_used, ev_free;
+    double prof_ms[MGX_PROF_COUNT] = {0};
+    long long prof_launches[MGX_PROF_COUNT] = {0};
+    double fine_updates = 0.0;
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                  \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess)                                                           \
+            return (h)->fail(MGX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- profiling scopes ---------------------------------------------------------
+struct Prof {
+    mgx_solver* s; int idx = -1;
+    Prof(mgx_solver* s_, int cls, long long launches) : s(s_)
+    {
+        if (!s->cfg.profile) return;
+        EventPair p;
+        if (!s->ev_free.empty()) { p = s->ev_free.back(); s->ev_free.pop_back(); }
+        else { if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; }
+        p.cls = cls; p.launches = launches;
+        (void)hipEventRecord(p.a, s->stream);
+        s->ev_used.push_back(p);
+        idx = (int)s->ev_used.size() - 1;
+    }
+    ~Prof() { if (idx >= 0) (void)hipEventRecord(s->ev_used[idx].b, s->stream); }
+};
+
+int prof_collect(mgx_solver* s)
+{
+    if (s->ev_used.empty()) return MGX_OK;
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    for (auto& p : s->ev_used) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            s->prof_ms[p.cls] += ms;
+            s->prof_launches[p.cls] += p.launches;
+        }
+        s->ev_free.push_back(p);
+    }
+    s->ev_used.clear();
+    return MGX_OK;
+}
+
+// ---- typed operator launches ----------------------------------------------------
+template <typename T> constexpr int dtype_of() { return sizeof(T) == 8 ? MGX_DTYPE_F64 : MGX_DTYPE_F32; }
+
+template <typename T>
+void launch_jacobi(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
+                   double omega, int rpc, hipStream_t st)
+{
+    if (row_hi <= row_lo) return;
+    const Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, rpc);
+    // PS:127, 138-140: the float path evaluates the scalars in double from the
+    // float omega and narrows them
+    const T om = (T)omega;
+    const T c0 = (T)(1.0 - (double)om);
+    const T c1 = (T)((double)om / 4.0);
+    hipLaunchKernelGGL((k_jacobi<T>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
+                       row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1);
+}
+
+template <typename T>
+void launch_rbgs(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
+                 int row_parity, int bnd_lo, int bnd_hi, int rpc, hipStream_t st)
+{
+    if (row_hi <= row_lo) return;
+    const Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, rpc);
+    hipLaunchKernelGGL((k_rbgs<T>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
+                       row_lo, row_hi, g.R, g.strips, g.chunks, row_parity, bnd_lo, bnd_hi);
+}
+
+template <typename T>
+void launch_restrict(const T* v, const T* b, T* cb, T* czero, int N, long pitch, long cpitch,
+                     int crow_lo, int crow_hi, int fine_row_off, int mode, bool fused, int rpc, hipStream_t st)
+{
+    if (crow_hi <= crow_lo) return;
+    Launch g = make_launch(N, VecOf<T>::W, crow_hi - crow_lo, rpc > 0 ? (rpc + 1) / 2 : 0);
+    const T w = (mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
+    if (fused)
+        hipLaunchKernelGGL((k_restrict<T, true>), dim3(g.blocks), dim3(kBlock), 0, st, v, b, cb, czero, N, pitch,
+                           cpitch, crow_lo, crow_hi, fine_row_off, g.R, g.strips, g.chunks, w);
+    else
+        hipLaunchKernelGGL((k_restrict<T, false>), dim3(g.blocks), dim3(kBlock), 0, st, v, b, cb, czero, N, pitch,
+                           cpitch, crow_lo, crow_hi, fine_row_off, g.R, g.strips, g.chunks, w);
+}
+
+template <typename T>
+void launch_prolong(T* v, const T* e, int N, long pitch, long cpitch, int row_lo, int row_hi,
+                    int fine_row_off, bool add, int rpc, hipStream_t st)
+{
+    if (row_hi <= row_lo) return;
+    const Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, rpc);
+    if (add)
+        hipLaunchKernelGGL((k_prolong<T, true>), dim3(g.blocks), dim3(kBlock), 0, st, v, e, N, pitch, cpitch,
+                           row_lo, row_hi, fine_row_off, g.R, g.strips, g.chunks);
+    else
+        hipLaunchKernelGGL((k_prolong<T, false>), dim3(g.blocks), dim3(kBlock), 0, st, v, e, N, pitch, cpitch,
+                           row_lo, row_hi, fine_row_off, g.R, g.strips, g.chunks);
+}
+
+// blocks needed by the sum-of-squares kernel for a given geometry
+template <typename T> long sumsq_blocks(int N, int rows, int rpc)
+{
+    return make_launch(N, VecOf<T>::W, rows, rpc).blocks;
+}
+
+// sum (b - A u)^2 over rows -> sum_dev[0]; MODE 2 also writes scaled float residual
+template <typename T, int MODE>
+void launch_residual(const T* v, const T* b, void* out, long pitch_out, double* partial, double* sum_dev,
+                     double inv_scale, int N, long pitch, int row_lo, int row_hi, int rpc, hipStream_t st,
+                     long partial_cap = -1)
+{
+    Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, rpc);
+    if (MODE != 0 && partial_cap >= 0 && g.blocks > partial_cap) {
+        // never write past the partial-sum buffer: fall back to taller chunks
+        const int R = (int)(((long)g.strips * (row_hi - row_lo) / kWavesPerBlock + partial_cap - 9) / (partial_cap - 8)) + 1;
+        g = make_launch(N, VecOf<T>::W, row_hi - row_lo, R);
+    }
+    hipLaunchKernelGGL((k_residual<T, MODE>), dim3(g.blocks), dim3(kBlock), 0, st, v, b, out, pitch_out, partial,
+                       inv_scale, N, pitch, row_lo, row_hi, g.R, g.strips, g.chunks);
+    if (MODE != 0)
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, st, partial, g.blocks, sum_dev);
+}
+
+// ---- device-side fills -------------------------------------------------------------
+template <typename T>
+__global__ void k_fill_rhs(T* b, int N, long pitch, int kind, double f)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c > N || r > N) return;
+    const double h = 1.0 / (double)N;
+    double v = 0.0;
+    if (r >= 1 && r < N && c >= 1 && c < N) {
+        if (kind == 0) v = f * h * h;                                   // PS:283-335 (sign: D1)
+        else v = h * h * 8.0 * 9.869604401089358 * sinpi(2.0 * c * h) * sinpi(2.0 * r * h);
+    }
+    b[(long)r * pitch + c] = (T)v;
+}
+
+__device__ inline uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+template <typename T>
+__global__ void k_fill_random(T* u, int N, long pitch, uint64_t seed)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c > N || r > N) return;
+    double v = 0.0;
+    if (r >= 1 && r < N && c >= 1 && c < N) {
+        const uint64_t idx = (uint64_t)(r - 1) * (uint64_t)(N - 1) + (uint64_t)(c - 1);  // PS:227 numbering
+        const uint64_t x = splitmix64(seed ^ splitmix64(idx));
+        v = (double)(x >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+    }
+    u[(long)r * pitch + c] = (T)v;
+}
+
+// ---- level helpers ------------------------------------------------------------------
+int alloc_level(mgx_solver* s, Level& l, int level, bool f64)
+{
+    l.L = level;
+    l.N = 1 << level;
+    l.rows = l.N + 1;
+    l.f64 = f64;
+    l.pitch = level_pitch(level, f64 ? MGX_DTYPE_F64 : MGX_DTYPE_F32);
+    l.bytes = (size_t)l.rows * (size_t)l.pitch * l.esize();
+    for (void** p : {&l.u, &l.b, &l.tmp}) {
+        if (hipMalloc(p, l.bytes) != hipSuccess) return s->fail(MGX_ERR_ALLOC, "hipMalloc failed for level arrays");
+        HIPCHK(s, hipMemsetAsync(*p, 0, l.bytes, s->stream));
+    }
+    return MGX_OK;
+}
+
+void free_level(Level& l)
+{
+    for (void** p : {&l.u, &l.b, &l.tmp, &l.r}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+}
+
+int ensure_r(mgx_solver* s, Level& l)
+{
+    if (l.r) return MGX_OK;
+    if (hipMalloc(&l.r, l.bytes) != hipSuccess) return s->fail(MGX_ERR_ALLOC, "hipMalloc failed for residual array");
+    HIPCHK(s, hipMemsetAsync(l.r, 0, l.bytes, s->stream));
+    return MGX_OK;
+}
+
+bool level_ok(const mgx_solver* s, int level)
+{
+    return level >= s->cfg.coarsest_level && level <= s->cfg.finest_level;
+}
+
+// interior (n x n, reference layout) <-> padded grid
+int copy_in(mgx_solver* s, Level& l, void* dst_grid, const void* src, size_t count)
+{
+    const size_t n = (size_t)l.N - 1;
+    if (count != n * n) return s->fail(MGX_ERR_INVALID, "vector length must be n*n with n = 2^level - 1");
+    const size_t es = l.esize();
+    char* d = reinterpret_cast<char*>(dst_grid) + ((size_t)l.pitch + 1) * es;   // (row 1, col 1)
+    HIPCHK(s, hipMemcpy2DAsync(d, (size_t)l.pitch * es, src, n * es, n * es, n, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    return MGX_OK;
+}
+
+int copy_out(mgx_solver* s, Level& l, const void* src_grid, void* dst, size_t count)
+{
+    const size_t n = (size_t)l.N - 1;
+    if (count != n * n) return s->fail(MGX_ERR_INVALID, "vector length must be n*n with n = 2^level - 1");
+    const size_t es = l.esize();
+    const char* p = reinterpret_cast<const char*>(src_grid) + ((size_t)l.pitch + 1) * es;
+    HIPCHK(s, hipMemcpy2DAsync(dst, n * es, p, (size_t)l.pitch * es, n * es, n, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    return MGX_OK;
+}
+
+// ---- operators on the working hierarchy -----------------------------------------------
+template <typename T>
+void smooth_t(mgx_solver* s, Level& l, int mu)
+{
+    const int rpc = s->rows_per_chunk;
+    for (int k = 0; k < mu; ++k) {
+        if (s->cfg.smoother == MGX_SMOOTHER_RBGS)
+            launch_rbgs<T>((const T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, 1, l.N, 0, 0, l.N, rpc, s->stream);
+        else
+            launch_jacobi<T>((const T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, 1, l.N, s->cfg.omega, rpc, s->stream);
+        std::swap(l.u, l.tmp);
+    }
+}
+
+void smooth(mgx_solver* s, int level, int mu)
+{
+    if (mu <= 0) return;
+    Level& l = s->lv[level];
+    const bool fine = (level == s->cfg.finest_level);
+    Prof p(s, fine ? MGX_PROF_SMOOTH_FINE : MGX_PROF_COARSE, mu);
+    if (l.f64) smooth_t<double>(s, l, mu); else smooth_t<float>(s, l, mu);
+    if (fine) s->fine_updates += (double)mu * (double)(l.N - 1) * (double)(l.N - 1);
+}
+
+// B[level-1] = R (B - A U)[level]  (fused = true)  or  R B[level]  (fused = false)
+void restrict_level(mgx_solver* s, int level, bool fused, bool zero_guess)
+{
+    Level& f = s->lv[level];
+    Level& c = s->lv[level - 1];
+    const bool fine = (level == s->cfg.finest_level);
+    Prof p(s, fine ? MGX_PROF_RESTRICT_FINE : MGX_PROF_COARSE, 1);
+    const int rpc = s->rows_per_chunk;
+    if (f.f64)
+        launch_restrict<double>((const double*)f.u, (const double*)f.b, (double*)c.b, zero_guess ? (double*)c.u : nullptr,
+                                f.N, f.pitch, c.pitch, 1, c.N, 0, s->cfg.restrict_mode, fused, rpc, s->stream);
+    else
+        launch_restrict<float>((const float*)f.u, (const float*)f.b, (float*)c.b, zero_guess ? (float*)c.u : nullptr,
+                               f.N, f.pitch, c.pitch, 1, c.N, 0, s->cfg.restrict_mode, fused, rpc, s->stream);
+}
+
+void prolong_level(mgx_solver* s, int level, bool add)
+{
+    Level& f = s->lv[level];
+    Level& c = s->lv[level - 1];
+    const bool fine = (level == s->cfg.finest_level);
+    Prof p(s, fine ? MGX_PROF_PROLONG_FINE : MGX_PROF_COARSE, 1);
+    const int rpc = s->rows_per_chunk;
+    if (f.f64)
+        launch_prolong<double>((double*)f.u, (const double*)c.u, f.N, f.pitch, c.pitch, 1, f.N, 0, add, rpc, s->stream);
+    else
+        launch_prolong<float>((float*)f.u, (const float*)c.u, f.N, f.pitch, c.pitch, 1, f.N, 0, add, rpc, s->stream);
+}
+
+void bottom_solve(mgx_solver* s)
+{
+    Level& l = s->lv[s->cfg.coarsest_level];
+    Prof p(s, (l.L == s->cfg.finest_level) ? MGX_PROF_SMOOTH_FINE : MGX_PROF_COARSE, 4);
+    if (l.f64) s->bottom.solve<double>((const double*)l.b, (double*)l.u, l.pitch, s->stream);
+    else s->bottom.solve<float>((const float*)l.b, (float*)l.u, l.pitch, s->stream);
+}
+
+// PS:575-627 / MF:132-173
+void vcycle(mgx_solver* s, int level)
+{
+    if (level == s->cfg.coarsest_level) {
+        if (s->cfg.bottom == MGX_BOTTOM_EXACT) {
+            bottom_solve(s);                                  // MF:137-139
+        } else {
+            smooth(s, level, s->cfg.mu1);                     // PS:581
+            smooth(s, level, s->cfg.mu2);                     // PS:585
+        }
+        return;
+    }
+    smooth(s, level, s->cfg.mu1);                             // PS:581
+    restrict_level(s, level, true, true);                     // PS:604-613
+    vcycle(s, level - 1);                                     // PS:617
+    prolong_level(s, level, true);                            // PS:620-624
+    smooth(s, level, s->cfg.mu2);                             // PS:625
+}
+
+int zero_u(mgx_solver* s, int level)
+{
+    Level& l = s->lv[level];
+    HIPCHK(s, hipMemsetAsync(l.u, 0, l.bytes, s->stream));
+    return MGX_OK;
+}
+
+// PS:629-650 / MF:175-191 on the working hierarchy (B[finest] must be set)
+int fmg(mgx_solver* s)
+{
+    const int lo = s->cfg.coarsest_level, hi = s->cfg.finest_level;
+    for (int l = hi; l > lo; --l) restrict_level(s, l, false, false);        // PS:641
+    if (s->cfg.bottom == MGX_BOTTOM_EXACT) {
+        bottom_solve(s);                                                     // MF:178-181
+    } else {
+        int rc = zero_u(s, lo);                                              // PS:630
+        if (rc) return rc;
+        for (int i = 0; i <= s->cfg.mu0; ++i) vcycle(s, lo);                 // PS:635
+    }
+    for (int l = lo + 1; l <= hi; ++l) {
+        prolong_level(s, l, false);                                          // PS:645
+        for (int i = 0; i <= s->cfg.mu0; ++i) vcycle(s, l);                  // PS:646-648
+    }
+    return MGX_OK;
+}
+
+// ||B - A U|| of an arbitrary grid pair (double or float)
+int residual_norm_grid(mgx_solver* s, const Level& l, const void* u, const void* b, double* out, int cls)
+{
+    {
+        Prof p(s, cls, 2);
+        if (l.f64)
+            launch_residual<double, 1>((const double*)u, (const double*)b, nullptr, 0, s->partial, s->sum_dev, 1.0,
+                                       l.N, l.pitch, 1, l.N, s->rows_per_chunk, s->stream, s->partial_cap);
+        else
+            launch_residual<float, 1>((const float*)u, (const float*)b, nullptr, 0, s->partial, s->sum_dev, 1.0,
+                                      l.N, l.pitch, 1, l.N, s->rows_per_chunk, s->stream, s->partial_cap);
+    }
+    HIPCHK(s, hipMemcpyAsync(s->sum_host, s->sum_dev, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    *out = std::sqrt(*s->sum_host);
+    return MGX_OK;
+}
+
+double pow2_floor(double x)
+{
+    int e;
+    (void)std::frexp(x, &e);
+    return std::ldexp(1.0, e - 1);
+}
+
+Level* pick(mgx_solver* s, int level, int which, void** grid)
+{
+    Level* l = &s->lv[level];
+    if (s->mixed && level == s->cfg.finest_level) l = &s->fine64;
+    switch (which) {
+        case MGX_VEC_U: *grid = l->u; break;
+        case MGX_VEC_B: *grid = l->b; break;
+        case MGX_VEC_R: *grid = l->r; break;
+        default: *grid = nullptr;
+    }
+    return l;
+}
+
+} // namespace
+
+// =====================================================================================
+// C-ABI
+// =====================================================================================
+extern "C" {
+
+int mgx_config_default(mgx_config* c)
+{
+    if (!c) return MGX_ERR_INVALID;
+    c->finest_level = 10;      // PS:17
+    c->coarsest_level = 7;     // PS:18
+    c->mu0 = 30;               // PS:20
+    c->mu1 = 10;               // PS:21
+    c->mu2 = 10;               // PS:22
+    c->omega = 2.0 / 3.0;      // PS:127
+    c->smoother = MGX_SMOOTHER_JACOBI;
+    c->dtype = MGX_DTYPE_F64;
+    c->schedule = MGX_SCHEDULE_FMG;   // PS:727
+    c->restrict_mode = MGX_RESTRICT_CONSISTENT;
+    c->bottom = MGX_BOTTOM_EXACT;
+    c->device = 0;
+    c->profile = 0;
+    return MGX_OK;
+}
+
+const char* mgx_status_string(int st)
+{
+    switch (st) {
+        case MGX_OK: return "ok";
+        case MGX_ERR_INVALID: return "invalid argument";
+        case MGX_ERR_NO_DEVICE: return "no usable HIP device";
+        case MGX_ERR_HIP: return "HIP runtime error";
+        case MGX_ERR_ALLOC: return "device allocation failed";
+        case MGX_ERR_STATE: return "invalid state";
+        default: return "unknown status";
+    }
+}
+
+const char* mgx_last_error(mgx_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mgx_level_n(int level) { return (level >= 1 && level < 31) ? (1 << level) - 1 : -1; }
+
+long mgx_level_pitch(int level, int dtype)
+{
+    if (level < 1 || level > 20 || (dtype != MGX_DTYPE_F32 && dtype != MGX_DTYPE_F64)) return -1;
+    return level_pitch(level, dtype);
+}
+
+int mgx_create(const mgx_config* cfg, mgx_handle* out)
+{
+    if (!cfg || !out) { g_create_error = "null argument"; return MGX_ERR_INVALID; }
+    *out = nullptr;
+    // level 2 (N = 4) is the smallest grid whose rows hold whole 16-byte vectors
+    // in both precisions; level 8 (255^2) bounds the dense sine-transform solve.
+    if (cfg->coarsest_level < 2 || cfg->finest_level < cfg->coarsest_level || cfg->finest_level > 15 ||
+        cfg->mu0 < 0 || cfg->mu1 < 0 || cfg->mu2 < 0 || !(cfg->omega > 0.0 && cfg->omega < 2.0) ||
+        cfg->smoother < 0 || cfg->smoother > 1 || cfg->dtype < 0 || cfg->dtype > 2 ||
+        cfg->schedule < 0 || cfg->schedule > 1 || cfg->restrict_mode < 0 || cfg->restrict_mode > 1 ||
+        cfg->bottom < 0 || cfg->bottom > 1) {
+        g_create_error = "invalid configuration";
+        return MGX_ERR_INVALID;
+    }
+    if (cfg->bottom == MGX_BOTTOM_EXACT && cfg->coarsest_level > 8) {
+        g_create_error = "exact bottom solve supports coarsest_level <= 8";
+        return MGX_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+        g_create_error = "no usable HIP device (libmgx has no CPU fallback)";
+        return MGX_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return MGX_ERR_HIP; }
+
+    mgx_solver* s = new (std::nothrow) mgx_solver();
+    if (!s) { g_create_error = "out of host memory"; return MGX_ERR_ALLOC; }
+    s->cfg = *cfg;
+    s->mixed = (cfg->dtype == MGX_DTYPE_MIXED);
+    s->work_f64 = (cfg->dtype == MGX_DTYPE_F64);
+    s->rows_per_chunk = env_int("MGX_ROWS", 0);
+    int rc = MGX_OK;
+    auto bail = [&](int code) { g_create_error = s->err; mgx_destroy(s); return code; };
+    if (hipStreamCreate(&s->stream) != hipSuccess) { s->err = "hipStreamCreate failed"; return bail(MGX_ERR_HIP); }
+    s->lv.resize(cfg->finest_level + 1);
+    for (int l = cfg->coarsest_level; l <= cfg->finest_level; ++l)
+        if ((rc = alloc_level(s, s->lv[l], l, s->work_f64)) != MGX_OK) return bail(rc);
+    if (s->mixed && (rc = alloc_level(s, s->fine64, cfg->finest_level, true)) != MGX_OK) return bail(rc);
+    if (s->mixed) { (void)hipFree(s->fine64.tmp); s->fine64.tmp = nullptr; }
+    // partial sums: the largest launch any norm kernel can make on the finest level
+    {
+        const int N = 1 << cfg->finest_level;
+        long cap = 0;
+        for (int rpc : {s->rows_per_chunk, 1}) {
+            cap = std::max(cap, sumsq_blocks<double>(N, N, rpc));
+            cap = std::max(cap, sumsq_blocks<float>(N, N, rpc));
+        }
+        s->partial_cap = cap + 8;
+        if (hipMalloc(&s->partial, s->partial_cap * sizeof(double)) != hipSuccess ||
+            hipMalloc(&s->sum_dev, sizeof(double)) != hipSuccess ||
+            hipHostMalloc(&s->sum_host, sizeof(double)) != hipSuccess) {
+            s->err = "allocation of reduction buffers failed";
+            return bail(MGX_ERR_ALLOC);
+        }
+    }
+    if (cfg->bottom == MGX_BOTTOM_EXACT) {
+        if (s->bottom.init((1 << cfg->coarsest_level) - 1) != hipSuccess) {
+            s->err = "bottom solver allocation failed";
+            return bail(MGX_ERR_ALLOC);
+        }
+    }
+    if (hipStreamSynchronize(s->stream) != hipSuccess) { s->err = "device initialisation failed"; return bail(MGX_ERR_HIP); }
+    *out = s;
+    return MGX_OK;
+}
+
+int mgx_destroy(mgx_handle s)
+{
+    if (!s) return MGX_OK;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (auto& l : s->lv) free_level(l);
+    free_level(s->fine64);
+    s->bottom.destroy();
+    if (s->partial) (void)hipFree(s->partial);
+    if (s->sum_dev) (void)hipFree(s->sum_dev);
+    if (s->sum_host) (void)hipHostFree(s->sum_host);
+    for (auto& p : s->ev_used) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& p : s->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return MGX_OK;
+}
+
+int mgx_synchronize(mgx_handle s)
+{
+    if (!s) return MGX_ERR_INVALID;
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    return MGX_OK;
+}
+
+// ---- data ---------------------------------------------------------------------------
+int mgx_set_level(mgx_handle s, int level, int which, const void* src, size_t count)
+{
+    if (!s || !src) return MGX_ERR_INVALID;
+    if (!level_ok(s, level)) return s->fail(MGX_ERR_INVALID, "level out of range");
+    void* grid = nullptr;
+    Level* l = pick(s, level, which, &grid);
+    if (which == MGX_VEC_R) {
+        int rc = ensure_r(s, *l);
+        if (rc) return rc;
+        grid = l->r;
+    }
+    if (!grid) return s->fail(MGX_ERR_INVALID, "unknown vector selector");
+    return copy_in(s, *l, grid, src, count);
+}
+
+int mgx_get_level(mgx_handle s, int level, int which, void* dst, size_t count)
+{
+    if (!s || !dst) return MGX_ERR_INVALID;
+    if (!level_ok(s, level)) return s->fail(MGX_ERR_INVALID, "level out of range");
+    void* grid = nullptr;
+    Level* l = pick(s, level, which, &grid);
+    if (!grid) return s->fail(MGX_ERR_STATE, "vector not available (call mgx_residual first for MGX_VEC_R)");
+    return copy_out(s, *l, grid, dst, count);
+}
+
+int mgx_set_rhs(mgx_handle s, const void* b, size_t count) { return s ? mgx_set_level(s, s->cfg.finest_level, MGX_VEC_B, b, count) : MGX_ERR_INVALID; }
+int mgx_set_guess(mgx_handle s, const void* u, size_t count) { return s ? mgx_set_level(s, s->cfg.finest_level, MGX_VEC_U, u, count) : MGX_ERR_INVALID; }
+int mgx_get_solution(mgx_handle s, void* u, size_t count) { return s ? mgx_get_level(s, s->cfg.finest_level, MGX_VEC_U, u, count) : MGX_ERR_INVALID; }
+
+int mgx_fill_rhs(mgx_handle s, int kind, double f)
+{
+    if (!s) return MGX_ERR_INVALID;
+    if (kind < 0 || kind > 1) return s->fail(MGX_ERR_INVALID, "unknown rhs kind");
+    void* grid = nullptr;
+    Level* l = pick(s, s->cfg.finest_level, MGX_VEC_B, &grid);
+    const dim3 blk(256), grd((l->N + 1 + 255) / 256, l->N + 1);
+    if (l->f64) hipLaunchKernelGGL(k_fill_rhs<double>, grd, blk, 0, s->stream, (double*)grid, l->N, l->pitch, kind, f);
+    else hipLaunchKernelGGL(k_fill_rhs<float>, grd, blk, 0, s->stream, (float*)grid, l->N, l->pitch, kind, f);
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    return MGX_OK;
+}
+
+int mgx_fill_guess_random(mgx_handle s, uint64_t seed)
+{
+    if (!s) return MGX_ERR_INVALID;
+    void* grid = nullptr;
+    Level* l = pick(s, s->cfg.finest_level, MGX_VEC_U, &grid);
+    const dim3 blk(256), grd((l->N + 1 + 255) / 256, l->N + 1);
+    if (l->f64) hipLaunchKernelGGL(k_fill_random<double>, grd, blk, 0, s->stream, (double*)grid, l->N, l->pitch, seed);
+    else hipLaunchKernelGGL(k_fill_random<float>, grd, blk, 0, s->stream, (float*)grid, l->N, l->pitch, seed);
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    return MGX_OK;
+}
+
+// ---- operators ------------------------------------------------------------------------
+#define OP_PROLOGUE(lvl_min)                                                              \
+    if (!s) return MGX_ERR_INVALID;                                                       \
+    if (level < (lvl_min) || level > s->cfg.finest_level)                                 \
+        return s->fail(MGX_ERR_INVALID, "level out of range for this operator");
+
+#define OP_EPILOGUE                                                                       \
+    HIPCHK(s, hipGetLastError());                                                         \
+    HIPCHK(s, hipStreamSynchronize(s->stream));                                           \
+    return MGX_OK;
+
+int mgx_smooth(mgx_handle s, int level, int mu)
+{
+    OP_PROLOGUE(s->cfg.coarsest_level)
+    if (mu < 0) return s->fail(MGX_ERR_INVALID, "mu must be >= 0");
+    smooth(s, level, mu);
+    OP_EPILOGUE
+}
+
+int mgx_residual(mgx_handle s, int level)
+{
+    OP_PROLOGUE(s->cfg.coarsest_level)
+    Level& l = s->lv[level];
+    int rc = ensure_r(s, l);
+    if (rc) return rc;
+    if (l.f64)
+        launch_residual<double, 0>((const double*)l.u, (const double*)l.b, l.r, l.pitch, nullptr, nullptr, 1.0, l.N,
+                                   l.pitch, 1, l.N, s->rows_per_chunk, s->stream);
+    else
+        launch_residual<float, 0>((const float*)l.u, (const float*)l.b, l.r, l.pitch, nullptr, nullptr, 1.0, l.N,
+                                  l.pitch, 1, l.N, s->rows_per_chunk, s->stream);
+    OP_EPILOGUE
+}
+
+int mgx_restrict(mgx_handle s, int level)
+{
+    OP_PROLOGUE(s->cfg.coarsest_level + 1)
+    restrict_level(s, level, true, true);
+    OP_EPILOGUE
+}
+
+int mgx_restrict_rhs(mgx_handle s, int level)
+{
+    OP_PROLOGUE(s->cfg.coarsest_level + 1)
+    restrict_level(s, level, false, false);
+    OP_EPILOGUE
+}
+
+int mgx_prolong_add(mgx_handle s, int level)
+{
+    OP_PROLOGUE(s->cfg.coarsest_level + 1)
+    prolong_level(s, level, true);
+    OP_EPILOGUE
+}
+
+int mgx_prolong(mgx_handle s, int level)
+{
+    OP_PROLOGUE(s->cfg.coarsest_level + 1)
+    prolong_level(s, level, false);
+    OP_EPILOGUE
+}
+
+int mgx_bottom_solve(mgx_handle s)
+{
+    if (!s) return MGX_ERR_INVALID;
+    if (s->cfg.bottom != MGX_BOTTOM_EXACT) return s->fail(MGX_ERR_STATE, "handle was created with bottom = SMOOTH");
+    bottom_solve(s);
+    OP_EPILOGUE
+}
+
+int mgx_residual_norm(mgx_handle s, int level, double* out)
+{
+    if (!s || !out) return MGX_ERR_INVALID;
+    if (!level_ok(s, level)) return s->fail(MGX_ERR_INVALID, "level out of range");
+    void* gu = nullptr; void* gb = nullptr;
+    Level* l = pick(s, level, MGX_VEC_U, &gu);
+    (void)pick(s, level, MGX_VEC_B, &gb);
+    return residual_norm_grid(s, *l, gu, gb, out, level == s->cfg.finest_level ? MGX_PROF_NORM_FINE : MGX_PROF_COARSE);
+}
+
+int mgx_vcycle(mgx_handle s, int level)
+{
+    OP_PROLOGUE(s->cfg.coarsest_level)
+    vcycle(s, level);
+    OP_EPILOGUE
+}
+
+int mgx_fmg(mgx_handle s)
+{
+    if (!s) return MGX_ERR_INVALID;
+    int rc = fmg(s);
+    if (rc) return rc;
+    OP_EPILOGUE
+}
+
+// ---- solve ----------------------------------------------------------------------------
+int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double* history, int history_cap)
+{
+    if (!s || max_cycles < 0 || !(tol >= 0.0)) return MGX_ERR_INVALID;
+    const int L = s->cfg.finest_level;
+    const bool do_fmg = (s->cfg.schedule == MGX_SCHEDULE_FMG);
+    std::vector<double> hist;
+    hist.reserve(max_cycles + 1);
+    s->fine_updates = 0.0;
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = MGX_OK;
+    double r = 0.0;
+    int k = 0;
+
+    if (!s->mixed) {
+        Level& l = s->lv[L];
+        if ((rc = residual_norm_grid(s, l, l.u, l.b, &r, MGX_PROF_NORM_FINE))) return rc;
+        hist.push_back(r);
+        for (k = 0; k < max_cycles; ++k) {
+            if (hist[k] <= tol * hist[0]) break;
+            if (k == 0 && do_fmg) { if ((rc = fmg(s))) return rc; }
+            else vcycle(s, L);
+            if ((rc = residual_norm_grid(s, l, l.u, l.b, &r, MGX_PROF_NORM_FINE))) return rc;
+            hist.push_back(r);
+        }
+    } else {
+        // BASELINE config 5: double residual and solution, float inner cycle on
+        // the residual scaled by a power of two near its rms (exact scaling).
+        Level& w = s->lv[L];            // float: u = e32, b = r32
+        Level& d = s->fine64;           // double: u, b
+        const double n = (double)(w.N - 1);
+        const int rpc = s->rows_per_chunk;
+        if ((rc = residual_norm_grid(s, d, d.u, d.b, &r, MGX_PROF_NORM_FINE))) return rc;
+        hist.push_back(r);
+        for (k = 0; k < max_cycles; ++k) {
+            if (hist[k] <= tol * hist[0]) break;
+            const Launch g = make_launch(d.N, 2, d.N - 1, rpc);
+            if (k == 0 && do_fmg) {
+                // ||b||: residual norm against a zero guess (FMG discards the guess, PS:630)
+                HIPCHK(s, hipMemsetAsync(d.u, 0, d.bytes, s->stream));
+                double bn = 0.0;
+                if ((rc = residual_norm_grid(s, d, d.u, d.b, &bn, MGX_PROF_NORM_FINE))) return rc;
+                const double scale = pow2_floor(bn / n);
+                hipLaunchKernelGGL(k_scale_f64_to_f32, dim3(g.blocks), dim3(kBlock), 0, s->stream, (float*)w.b,
+                                   (const double*)d.b, 1.0 / scale, d.N, d.pitch, w.pitch, 1, d.N, g.R, g.strips, g.chunks);
+                if ((rc = fmg(s))) return rc;
+                hipLaunchKernelGGL(k_axpy_f32_to_f64, dim3(g.blocks), dim3(kBlock), 0, s->stream, (double*)d.u,
+                                   (const float*)w.u, scale, d.N, d.pitch, w.pitch, 1, d.N, g.R, g.strips, g.chunks, 1);
+            } else {
+                const double scale = pow2_floor(hist[k > 0 ? k - 1 : 0] / n);
+                if (k == 0) {
+                    // no scaled residual is pending yet: produce it now
+                    Prof p(s, MGX_PROF_NORM_FINE, 2);
+                    launch_residual<double, 2>((const double*)d.u, (const double*)d.b, w.b, w.pitch, s->partial,
+                                               s->sum_dev, 1.0 / scale, d.N, d.pitch, 1, d.N, rpc, s->stream, s->partial_cap);
+                }
+                HIPCHK(s, hipMemsetAsync(w.u, 0, w.bytes, s->stream));          // PS:613-style zero guess
+                vcycle(s, L);
+                hipLaunchKernelGGL(k_axpy_f32_to_f64, dim3(g.blocks), dim3(kBlock), 0, s->stream, (double*)d.u,
+                                   (const float*)w.u, scale, d.N, d.pitch, w.pitch, 1, d.N, g.R, g.strips, g.chunks, 0);
+            }
+            // residual of the new iterate: its norm is hist[k+1]; the same pass
+            // writes the float residual the next cycle consumes, scaled by the
+            // power of two derived from hist[k] (known now).
+            {
+                const double next_scale = pow2_floor(hist[k] / n);
+                Prof p(s, MGX_PROF_NORM_FINE, 2);
+                launch_residual<double, 2>((const double*)d.u, (const double*)d.b, w.b, w.pitch, s->partial,
+                                           s->sum_dev, 1.0 / next_scale, d.N, d.pitch, 1, d.N, rpc, s->stream, s->partial_cap);
+            }
+            HIPCHK(s, hipMemcpyAsync(s->sum_host, s->sum_dev, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(s, hipStreamSynchronize(s->stream));
+            hist.push_back(std::sqrt(*s->sum_host));
+        }
+    }
+    HIPCHK(s, hipGetLastError());
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    if (stats) {
+        stats->cycles = k;
+        stats->initial_residual = hist.front();
+        stats->final_residual = hist.back();
+        stats->converged = (hist.back() <= tol * hist.front()) ? 1 : 0;
+        stats->seconds = std::chrono::duration<double>(t1 - t0).count();
+        stats->fine_updates = s->fine_updates;
+        stats->history_len = (int)hist.size();
+    }
+    if (history)
+        for (int i = 0; i < (int)hist.size() && i < history_cap; ++i) history[i] = hist[i];
+    return MGX_OK;
+}
+
+// ---- measurement ------------------------------------------------------------------------
+int mgx_profile_reset(mgx_handle s)
+{
+    if (!s) return MGX_ERR_INVALID;
+    int rc = prof_collect(s);
+    if (rc) return rc;
+    for (int i = 0; i < MGX_PROF_COUNT; ++i) { s->prof_ms[i] = 0.0; s->prof_launches[i] = 0; }
+    return MGX_OK;
+}
+
+int mgx_profile_get(mgx_handle s, mgx_profile* out)
+{
+    if (!s || !out) return MGX_ERR_INVALID;
+    int rc = prof_collect(s);
+    if (rc) return rc;
+    for (int i = 0; i < MGX_PROF_COUNT; ++i) { out->ms[i] = s->prof_ms[i]; out->launches[i] = s->prof_launches[i]; }
+    return MGX_OK;
+}
+
+int mgx_time_smoother(mgx_handle s, int sweeps, double* ms)
+{
+    if (!s || !ms || sweeps < 1) return MGX_ERR_INVALID;
+    hipEvent_t a, b;
+    HIPCHK(s, hipEventCreate(&a));
+    HIPCHK(s, hipEventCreate(&b));
+    Level& l = s->lv[s->cfg.finest_level];
+    HIPCHK(s, hipEventRecord(a, s->stream));
+    if (l.f64) smooth_t<double>(s, l, sweeps); else smooth_t<float>(s, l, sweeps);
+    HIPCHK(s, hipEventRecord(b, s->stream));
+    HIPCHK(s, hipEventSynchronize(b));
+    float f = 0.f;
+    HIPCHK(s, hipEventElapsedTime(&f, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms = f;
+    return MGX_OK;
+}
+
+// =====================================================================================
+// slab-level operators on caller-owned device memory
+// =====================================================================================
+static int slab_check(const mgx_slab* s)
+{
+    if (!s || s->level < 2 || s->level > 15 || s->rows < 1) return MGX_ERR_INVALID;
+    if (s->dtype != MGX_DTYPE_F32 && s->dtype != MGX_DTYPE_F64) return MGX_ERR_INVALID;
+    return MGX_OK;
+}
+
+long mgx_slab_scratch_doubles(const mgx_slab* s)
+{
+    if (slab_check(s)) return -1;
+    const int N = 1 << s->level;
+    const int rpc = env_int("MGX_ROWS", 0);
+    long cap = 0;
+    for (int r : {rpc, 1}) {
+        cap = std::max(cap, sumsq_blocks<double>(N, s->rows, r));
+        cap = std::max(cap, sumsq_blocks<float>(N, s->rows, r));
+    }
+    return cap + 8;
+}
+
+int mgx_slab_jacobi(const mgx_slab* s, void* u, const void* b, void* tmp, int row_lo, int row_hi, int mu,
+                    double omega, int shrink, int* result_in_tmp, void* stream)
+{
+    if (slab_check(s) || !u || !b || !tmp || mu < 0) return MGX_ERR_INVALID;
+    const int N = 1 << s->level;
+    const long pitch = level_pitch(s->level, s->dtype);
+    const int first = 1 - s->row0, last = N - s->row0;      // unknown rows are [first, last)
+    const int rpc = env_int("MGX_ROWS", 0);
+    void* src = u; void* dst = tmp;
+    for (int k = 0; k < mu; ++k) {
+        const int ext = shrink ? (mu - 1 - k) : 0;
+        const int lo = std::max(row_lo - ext, first), hi = std::min(row_hi + ext, last);
+        if (lo < 1 || hi > s->rows - 1) return MGX_ERR_INVALID;       // rows lo-1 and hi are read
+        if (s->dtype == MGX_DTYPE_F64)
+            launch_jacobi<double>((const double*)src, (const double*)b, (double*)dst, N, pitch, lo, hi, omega, rpc, (hipStream_t)stream);
+        else
+            launch_jacobi<float>((const float*)src, (const float*)b, (float*)dst, N, pitch, lo, hi, omega, rpc, (hipStream_t)stream);
+        std::swap(src, dst);
+    }
+    if (result_in_tmp) *result_in_tmp = (mu & 1);
+    return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_HIP;
+}
+
+int mgx_slab_rbgs(const mgx_slab* s, void* u, const void* b, void* tmp, int row_lo, int row_hi, int mu,
+                  int shrink, int* result_in_tmp, void* stream)
+{
+    if (slab_check(s) || !u || !b || !tmp || mu < 0) return MGX_ERR_INVALID;
+    const int N = 1 << s->level;
+    const long pitch = level_pitch(s->level, s->dtype);
+    const int bnd_lo = -s->row0, bnd_hi = N - s->row0;
+    const int rpc = env_int("MGX_ROWS", 0);
+    void* src = u; void* dst = tmp;
+    for (int k = 0; k < mu; ++k) {
+        const int ext = shrink ? 2 * (mu - 1 - k) : 0;
+        const int lo = std::max(row_lo - ext, bnd_lo + 1), hi = std::min(row_hi + ext, bnd_hi);
+        // rows lo-2 .. hi+1 are read unless they lie beyond a global boundary row
+        if (std::max(lo - 2, bnd_lo) < 0 || std::min(hi + 1, bnd_hi) > s->rows - 1) return MGX_ERR_INVALID;
+        if (s->dtype == MGX_DTYPE_F64)
+            launch_rbgs<double>((const double*)src, (const double*)b, (double*)dst, N, pitch, lo, hi, s->row0 & 1, bnd_lo, bnd_hi, rpc, (hipStream_t)stream);
+        else
+            launch_rbgs<float>((const float*)src, (const float*)b, (float*)dst, N, pitch, lo, hi, s->row0 & 1, bnd_lo, bnd_hi, rpc, (hipStream_t)stream);
+        std::swap(src, dst);
+    }
+    if (result_in_tmp) *result_in_tmp = (mu & 1);
+    return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_HIP;
+}
+
+int mgx_slab_restrict(const mgx_slab* f, const void* u, const void* b, const mgx_slab* c, void* cb, void* zero_u,
+                      int crow_lo, int crow_hi, int restrict_mode, int fused, void* stream)
+{
+    if (slab_check(f) || slab_check(c) || !b || !cb || (fused && !u)) return MGX_ERR_INVALID;
+    if (c->level != f->level - 1 || c->dtype != f->dtype) return MGX_ERR_INVALID;
+    const int N = 1 << f->level;
+    const long pitch = level_pitch(f->level, f->dtype), cpitch = level_pitch(c->level, c->dtype);
+    const int off = 2 * c->row0 - f->row0;
+    // coarse rows must be unknown rows; fine rows 2I+off-2 .. 2I+off+2 must exist (fused), +-1 otherwise
+    const int halo = fused ? 2 : 1;
+    if (crow_lo < 0 || crow_hi > c->rows || crow_lo + c->row0 < 1 || crow_hi + c->row0 > N / 2) return MGX_ERR_INVALID;
+    if (crow_hi > crow_lo && (2 * crow_lo + off - halo < 0 || 2 * (crow_hi - 1) + off + halo > f->rows - 1)) return MGX_ERR_INVALID;
+    const int rpc = env_int("MGX_ROWS", 0);
+    if (f->dtype == MGX_DTYPE_F64)
+        launch_restrict<double>((const double*)u, (const double*)b, (double*)cb, (double*)zero_u, N, pitch, cpitch,
+                                crow_lo, crow_hi, off, restrict_mode, fused != 0, rpc, (hipStream_t)stream);
+    else
+        launch_restrict<float>((const float*)u, (const float*)b, (float*)cb, (float*)zero_u, N, pitch, cpitch,
+                               crow_lo, crow_hi, off, restrict_mode, fused != 0, rpc, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_HIP;
+}
+
+int mgx_slab_prolong(const mgx_slab* f, void* u, const mgx_slab* c, const void* e, int row_lo, int row_hi, int add,
+                     void* stream)
+{
+    if (slab_check(f) || slab_check(c) || !u || !e) return MGX_ERR_INVALID;
+    if (c->level != f->level - 1 || c->dtype != f->dtype) return MGX_ERR_INVALID;
+    const int N = 1 << f->level;
+    const long pitch = level_pitch(f->level, f->dtype), cpitch = level_pitch(c->level, c->dtype);
+    const int off = 2 * c->row0 - f->row0;
+    if (row_lo < 0 || row_hi > f->rows || row_lo + f->row0 < 1 || row_hi + f->row0 > N) return MGX_ERR_INVALID;
+    if (row_hi > row_lo) {
+        const int ylo = row_lo - off, yhi = row_hi - 1 - off;
+        if (ylo < 0 || (yhi >> 1) + (yhi & 1) > c->rows - 1) return MGX_ERR_INVALID;
+    }
+    const int rpc = env_int("MGX_ROWS", 0);
+    if (f->dtype == MGX_DTYPE_F64)
+        launch_prolong<double>((double*)u, (const double*)e, N, pitch, cpitch, row_lo, row_hi, off, add != 0, rpc, (hipStream_t)stream);
+    else
+        launch_prolong<float>((float*)u, (const float*)e, N, pitch, cpitch, row_lo, row_hi, off, add != 0, rpc, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_HIP;
+}
+
+int mgx_slab_residual_sumsq(const mgx_slab* s, const void* u, const void* b, int row_lo, int row_hi,
+                            double* scratch, double* sum_dev, void* stream)
+{
+    if (slab_check(s) || !u || !b || !scratch || !sum_dev) return MGX_ERR_INVALID;
+    const int N = 1 << s->level;
+    const long pitch = level_pitch(s->level, s->dtype);
+    if (row_lo < 1 || row_hi > s->rows - 1 || row_lo + s->row0 < 1 || row_hi + s->row0 > N || row_hi <= row_lo) return MGX_ERR_INVALID;
+    const int rpc = env_int("MGX_ROWS", 0);
+    if (s->dtype == MGX_DTYPE_F64)
+        launch_residual<double, 1>((const double*)u, (const double*)b, nullptr, 0, scratch, sum_dev, 1.0, N, pitch, row_lo, row_hi, rpc, (hipStream_t)stream);
+    else
+        launch_residual<float, 1>((const float*)u, (const float*)b, nullptr, 0, scratch, sum_dev, 1.0, N, pitch, row_lo, row_hi, rpc, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_HIP;
+}
+
+} // extern "C"

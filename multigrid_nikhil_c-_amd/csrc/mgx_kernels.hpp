@@ -1,0 +1,605 @@
+// mgx_kernels.hpp — hand-written gfx950 (CDNA4, wave64) stencil kernels for the
+// 2-D Poisson multigrid hot path.  Device code only; launch wrappers at the end.
+//
+// What each kernel replaces in the reference (PS = Poissons_SYCL.cpp,
+// MF = Multigrid_functions.cpp):
+//   k_jacobi          PS:137-145  (gemv + scal + scal + add + add per sweep; K1-K5)
+//   k_rbgs            -- absent from the reference; SURVEY §8a row A8
+//   k_residual        PS:604-607  (2 gemv + add + sub; K6-K9)
+//   k_restrict        PS:531-546  restriction2d (fused with the residual when FUSED)
+//   k_prolong         PS:337-425  interpolation2d, + PS:623 correction add (K10)
+//   k_norm2_*         -- the reference reports no residual (D10)
+//
+// Storage (DESIGN.md "Data layout in HBM"): one level = the full node grid,
+// rows 0..N and columns 0..N with N = 2^L, *including* the zero Dirichlet ring
+// the reference eliminates (PS:188-198, 224).  Row pitch is a multiple of 256 B
+// so every row starts on a cache line; columns N+1..pitch-1 are zero padding.
+// A thread owns one 16-byte vector (2 doubles / 4 floats) of a row, a wave owns
+// 64 consecutive vectors, and every global access is a 16-byte access at a
+// 16-byte-aligned address.  Waves march down a chunk of rows keeping the
+// rolling row window in registers, so each value is read from HBM once; the
+// x-neighbours come from the adjacent lanes by wavefront shuffles, and the two
+// outermost lanes of a wave are halo lanes (they load and compute but never
+// store), which is what lets the red-black kernel update both colours in one
+// pass over the data.
+//
+// All loads are predicated on explicit bounds derived from (N, pitch, rows):
+// no kernel here can address outside its arrays whatever the launch geometry.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mgx {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;                 // 4 waves
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kOutLanes = kWave - 2;        // lanes 1..62 store; 0 and 63 are halo lanes
+
+template <typename T> struct VecOf;
+template <> struct VecOf<double> { using type = double2; static constexpr int W = 2; };
+template <> struct VecOf<float>  { using type = float4;  static constexpr int W = 4; };
+
+// ---- tiny vector helpers ----------------------------------------------------
+__device__ __forceinline__ double2 vzero(double2*) { return make_double2(0.0, 0.0); }
+__device__ __forceinline__ float4  vzero(float4*)  { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <typename V> __device__ __forceinline__ V vload(const void* p, bool pred)
+{
+    V z = vzero((V*)nullptr);
+    if (pred) z = *reinterpret_cast<const V*>(p);
+    return z;
+}
+template <typename V> __device__ __forceinline__ void vstore(void* p, const V& v, bool pred)
+{
+    if (pred) *reinterpret_cast<V*>(p) = v;
+}
+
+__device__ __forceinline__ double first(const double2& v) { return v.x; }
+__device__ __forceinline__ double last(const double2& v)  { return v.y; }
+__device__ __forceinline__ float  first(const float4& v)  { return v.x; }
+__device__ __forceinline__ float  last(const float4& v)   { return v.w; }
+
+// value held by the lane one to the left / right (wave64 shuffles).  Lane 0's
+// "left" and lane 63's "right" are don't-cares: those lanes never store.
+template <typename T> __device__ __forceinline__ T from_left(T x)  { return __shfl_up(x, 1, kWave); }
+template <typename T> __device__ __forceinline__ T from_right(T x) { return __shfl_down(x, 1, kWave); }
+
+// ---- wave -> (row chunk, column strip) --------------------------------------
+// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an XCD and its
+// L2).  The remap gives each XCD a contiguous range of tiles, x fastest, so the
+// halo rows and halo vectors a wave re-reads were fetched by a neighbour on the
+// same L2.  gridDim.x is always a multiple of 8 (launch wrappers round up).
+struct Tile { int chunk, strip; bool active; };
+
+__device__ __forceinline__ Tile wave_tile(int strips, int chunks)
+{
+    const int per_xcd = gridDim.x >> 3;
+    const int b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const long g = (long)b * kWavesPerBlock + (threadIdx.x >> 6);
+    Tile t;
+    t.chunk = (int)(g / strips);
+    t.strip = (int)(g - (long)t.chunk * strips);
+    t.active = t.chunk < chunks;
+    return t;
+}
+
+struct Cols {           // per-lane column bookkeeping, shared by all kernels
+    int vx;             // vector index of this lane in the row
+    long col;           // first column of the vector
+    bool ld;            // vector lies inside the row allocation
+    bool st;            // this lane stores (not a halo lane, holds interior columns)
+};
+
+template <int W> __device__ __forceinline__ Cols lane_cols(int strip, int N, long pitch)
+{
+    const int lane = threadIdx.x & 63;
+    Cols c;
+    c.vx = strip * kOutLanes - 1 + lane;
+    c.col = (long)c.vx * W;
+    c.ld = (c.vx >= 0) && (c.col + W <= pitch);
+    c.st = (lane >= 1) && (lane <= kOutLanes) && (c.vx < N / W);
+    return c;
+}
+
+// off-diagonal sum in the reference's CSR column order N, W, E, S (PS:138)
+template <typename T> __device__ __forceinline__ T nbr(T n, T w, T e, T s) { return ((n + w) + e) + s; }
+
+// =============================================================================
+// weighted Jacobi, one sweep, out of place:  vout = (1-w) v + (w/4) b + (w/4) S v
+//   arithmetic order of PS:138-142: t = c0*v + c1*b ; out = t + c1*(N+W+E+S).
+// Algorithmic HBM bytes per updated point: read v + read b + write v' = 3 sizeof(T).
+// Rows [row_lo,row_hi) are updated; rows row_lo-1 and row_hi are read only.
+// =============================================================================
+template <typename T>
+__device__ __forceinline__ typename VecOf<T>::type
+jacobi_vec(const typename VecOf<T>::type& up, const typename VecOf<T>::type& cur,
+           const typename VecOf<T>::type& dn, const typename VecOf<T>::type& bb, T c0, T c1);
+
+template <>
+__device__ __forceinline__ double2 jacobi_vec<double>(const double2& up, const double2& cur, const double2& dn,
+                                                      const double2& bb, double c0, double c1)
+{
+    const double l = from_left(cur.y), r = from_right(cur.x);
+    double2 o;
+    o.x = (c0 * cur.x + c1 * bb.x) + c1 * nbr(up.x, l, cur.y, dn.x);
+    o.y = (c0 * cur.y + c1 * bb.y) + c1 * nbr(up.y, cur.x, r, dn.y);
+    return o;
+}
+template <>
+__device__ __forceinline__ float4 jacobi_vec<float>(const float4& up, const float4& cur, const float4& dn,
+                                                    const float4& bb, float c0, float c1)
+{
+    const float l = from_left(cur.w), r = from_right(cur.x);
+    float4 o;
+    o.x = (c0 * cur.x + c1 * bb.x) + c1 * nbr(up.x, l, cur.y, dn.x);
+    o.y = (c0 * cur.y + c1 * bb.y) + c1 * nbr(up.y, cur.x, cur.z, dn.y);
+    o.z = (c0 * cur.z + c1 * bb.z) + c1 * nbr(up.z, cur.y, cur.w, dn.z);
+    o.w = (c0 * cur.w + c1 * bb.w) + c1 * nbr(up.w, cur.z, r, dn.w);
+    return o;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_jacobi(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
+         int N, long pitch, int row_lo, int row_hi, int R, int strips, int chunks, T c0, T c1)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int W = VecOf<T>::W;
+    const Tile t = wave_tile(strips, chunks);
+    if (!t.active) return;
+    const Cols c = lane_cols<W>(t.strip, N, pitch);
+    const int r0 = row_lo + t.chunk * R;
+    const int r1 = min(r0 + R, row_hi);
+    const T* pv = vin + c.col;
+    const T* pb = rhs + c.col;
+    T* po = vout + c.col;
+
+    V up = vload<V>(pv + (long)(r0 - 1) * pitch, c.ld);
+    V cur = vload<V>(pv + (long)r0 * pitch, c.ld);
+    V dn = vload<V>(pv + (long)(r0 + 1) * pitch, c.ld);
+    V bb = vload<V>(pb + (long)r0 * pitch, c.ld);
+    for (int r = r0; r < r1; ++r) {
+        // prefetch the next row before computing this one (r+2 <= row_hi+1 is
+        // never dereferenced past row_hi: predicate on r + 1 < r1)
+        const bool more = (r + 1 < r1);
+        const V dn2 = vload<V>(pv + (long)(r + 2) * pitch, c.ld && more);
+        const V bb2 = vload<V>(pb + (long)(r + 1) * pitch, c.ld && more);
+        V o = jacobi_vec<T>(up, cur, dn, bb, c0, c1);
+        if (c.vx == 0) o.x = (T)0;          // column 0 is the Dirichlet boundary
+        vstore<V>(po + (long)r * pitch, o, c.st);
+        up = cur; cur = dn; dn = dn2; bb = bb2;
+    }
+}
+
+// =============================================================================
+// red-black Gauss-Seidel, one full sweep (red then black), out of place in one
+// pass: vout = GS_black(GS_red(vin)).  Colour = parity of (global row + col),
+// red = even.  A wave keeps a 4-row window: to finish row r (black) it needs
+// the red-updated rows r-1, r, r+1, and red-updating row r+1 needs the old row
+// r+2.  Halo rows and halo lanes recompute the red update redundantly, so no
+// wave ever depends on another wave's output (no intra-launch hand-off).
+//   point update: v = 0.25 * (b + ((N + W) + E) + S)
+// row_parity: parity of the global index of local row 0 (slabs).
+// bnd_lo / bnd_hi: local indices of the global boundary rows 0 and N; rows at
+// or beyond them are never updated (stay 0) and never dereferenced beyond.
+// =============================================================================
+template <typename T, int COLOUR>
+__device__ __forceinline__ typename VecOf<T>::type
+gs_colour_vec(const typename VecOf<T>::type& up, const typename VecOf<T>::type& cur,
+              const typename VecOf<T>::type& dn, const typename VecOf<T>::type& bb, int par0);
+
+// par0 = parity of (global row + first column of the vector); the element e of
+// the vector is updated when ((par0 + e) & 1) == COLOUR.
+template <typename T, int COLOUR>
+__device__ __forceinline__ T gs_pick(T oldv, T newv, int par) { return ((par & 1) == COLOUR) ? newv : oldv; }
+
+template <int COLOUR>
+__device__ __forceinline__ double2 gs_colour_d(const double2& up, const double2& cur, const double2& dn,
+                                               const double2& bb, int par0)
+{
+    const double l = from_left(cur.y), r = from_right(cur.x);
+    double2 o;
+    o.x = gs_pick<double, COLOUR>(cur.x, 0.25 * (bb.x + nbr(up.x, l, cur.y, dn.x)), par0);
+    o.y = gs_pick<double, COLOUR>(cur.y, 0.25 * (bb.y + nbr(up.y, cur.x, r, dn.y)), par0 + 1);
+    return o;
+}
+template <int COLOUR>
+__device__ __forceinline__ float4 gs_colour_f(const float4& up, const float4& cur, const float4& dn,
+                                              const float4& bb, int par0)
+{
+    const float l = from_left(cur.w), r = from_right(cur.x);
+    float4 o;
+    o.x = gs_pick<float, COLOUR>(cur.x, 0.25f * (bb.x + nbr(up.x, l, cur.y, dn.x)), par0);
+    o.y = gs_pick<float, COLOUR>(cur.y, 0.25f * (bb.y + nbr(up.y, cur.x, cur.z, dn.y)), par0 + 1);
+    o.z = gs_pick<float, COLOUR>(cur.z, 0.25f * (bb.z + nbr(up.z, cur.y, cur.w, dn.z)), par0);
+    o.w = gs_pick<float, COLOUR>(cur.w, 0.25f * (bb.w + nbr(up.w, cur.z, r, dn.w)), par0 + 1);
+    return o;
+}
+template <int COLOUR> __device__ __forceinline__ double2
+gs_colour(const double2& u, const double2& c, const double2& d, const double2& b, int p) { return gs_colour_d<COLOUR>(u, c, d, b, p); }
+template <int COLOUR> __device__ __forceinline__ float4
+gs_colour(const float4& u, const float4& c, const float4& d, const float4& b, int p) { return gs_colour_f<COLOUR>(u, c, d, b, p); }
+
+// zero the columns that are not unknowns (column 0, and columns >= N)
+__device__ __forceinline__ void mask_cols(double2& v, long col, int N)
+{
+    if (col == 0) v.x = 0.0;
+    if (col >= N) { v.x = 0.0; v.y = 0.0; }
+}
+__device__ __forceinline__ void mask_cols(float4& v, long col, int N)
+{
+    if (col == 0) v.x = 0.f;
+    if (col >= N) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_rbgs(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
+       int N, long pitch, int row_lo, int row_hi, int R, int strips, int chunks,
+       int row_parity, int bnd_lo, int bnd_hi)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int W = VecOf<T>::W;
+    const Tile t = wave_tile(strips, chunks);
+    if (!t.active) return;
+    const Cols c = lane_cols<W>(t.strip, N, pitch);
+    const int r0 = row_lo + t.chunk * R;
+    const int r1 = min(r0 + R, row_hi);
+    const T* pv = vin + c.col;
+    const T* pb = rhs + c.col;
+    T* po = vout + c.col;
+    const V Z = vzero((V*)nullptr);
+    const int cpar = (int)(c.col & 1);      // col parity of element 0 (W is even)
+
+    // a row y may be read iff bnd_lo <= y <= bnd_hi; it is an unknown row iff
+    // bnd_lo < y < bnd_hi.
+    auto ldrow = [&](const T* base, int y) -> V {
+        return vload<V>(base + (long)y * pitch, c.ld && y >= bnd_lo && y <= bnd_hi);
+    };
+    // red update of row y given old rows y-1, y, y+1 (identity on boundary rows)
+    auto red = [&](const V& u, const V& m, const V& d, const V& b, int y) -> V {
+        V o = gs_colour<0>(u, m, d, b, row_parity + y + cpar);
+        mask_cols(o, c.col, N);
+        return (y > bnd_lo && y < bnd_hi) ? o : Z;
+    };
+
+    // window: A = red(row r-1), B = red(row r), O1 = old(row r+1), O2 = old(row r+2)
+    V o_m2 = ldrow(pv, r0 - 2), o_m1 = ldrow(pv, r0 - 1), o_0 = ldrow(pv, r0), o_p1 = ldrow(pv, r0 + 1);
+    V A = red(o_m2, o_m1, o_0, ldrow(pb, r0 - 1), r0 - 1);
+    V B = red(o_m1, o_0, o_p1, ldrow(pb, r0), r0);
+    V bcur = ldrow(pb, r0);
+    V O1 = o_p1;
+    V O0 = o_0;   // old row r (needed as "up" when red-updating row r+1)
+    for (int r = r0; r < r1; ++r) {
+        const V O2 = ldrow(pv, r + 2);
+        const V bnext = ldrow(pb, r + 1);
+        const V Cn = red(O0, O1, O2, bnext, r + 1);          // red(row r+1)
+        V o = gs_colour<1>(A, B, Cn, bcur, row_parity + r + cpar);   // black(row r)
+        mask_cols(o, c.col, N);
+        vstore<V>(po + (long)r * pitch, o, c.st);
+        A = B; B = Cn; O0 = O1; O1 = O2; bcur = bnext;
+    }
+}
+
+// =============================================================================
+// residual r = b - A v   (PS:604-607: Av = LU v + D v = -(N+W+E+S) + 4 v)
+// =============================================================================
+__device__ __forceinline__ double2 residual_vec(const double2& up, const double2& cur, const double2& dn, const double2& bb)
+{
+    const double l = from_left(cur.y), r = from_right(cur.x);
+    double2 o;
+    o.x = bb.x - (-nbr(up.x, l, cur.y, dn.x) + 4.0 * cur.x);
+    o.y = bb.y - (-nbr(up.y, cur.x, r, dn.y) + 4.0 * cur.y);
+    return o;
+}
+__device__ __forceinline__ float4 residual_vec(const float4& up, const float4& cur, const float4& dn, const float4& bb)
+{
+    const float l = from_left(cur.w), r = from_right(cur.x);
+    float4 o;
+    o.x = bb.x - (-nbr(up.x, l, cur.y, dn.x) + 4.f * cur.x);
+    o.y = bb.y - (-nbr(up.y, cur.x, cur.z, dn.y) + 4.f * cur.y);
+    o.z = bb.z - (-nbr(up.z, cur.y, cur.w, dn.z) + 4.f * cur.z);
+    o.w = bb.w - (-nbr(up.w, cur.z, r, dn.w) + 4.f * cur.w);
+    return o;
+}
+
+// MODE 0: store r (same type).  MODE 1: accumulate sum r^2 only.
+// MODE 2 (T = double): store (float)(r * inv_scale) into a float grid of pitch
+// pitch_out AND accumulate sum r^2  (the mixed-precision defect, config 5).
+template <typename T, int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_residual(const T* __restrict__ vin, const T* __restrict__ rhs, void* __restrict__ out, long pitch_out,
+           double* __restrict__ partial, double inv_scale,
+           int N, long pitch, int row_lo, int row_hi, int R, int strips, int chunks)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int W = VecOf<T>::W;
+    __shared__ double wsum[kWavesPerBlock];
+    const Tile t = wave_tile(strips, chunks);
+    double acc = 0.0;
+    if (t.active) {
+        const Cols c = lane_cols<W>(t.strip, N, pitch);
+        const int r0 = row_lo + t.chunk * R;
+        const int r1 = min(r0 + R, row_hi);
+        const T* pv = vin + c.col;
+        const T* pb = rhs + c.col;
+        V up = vload<V>(pv + (long)(r0 - 1) * pitch, c.ld);
+        V cur = vload<V>(pv + (long)r0 * pitch, c.ld);
+        for (int r = r0; r < r1; ++r) {
+            const V dn = vload<V>(pv + (long)(r + 1) * pitch, c.ld);
+            const V bb = vload<V>(pb + (long)r * pitch, c.ld);
+            V o = residual_vec(up, cur, dn, bb);
+            mask_cols(o, c.col, N);
+            if (MODE == 0) {
+                vstore<V>(reinterpret_cast<T*>(out) + c.col + (long)r * pitch, o, c.st);
+            } else {
+                if (c.st) {
+                    if constexpr (W == 2) acc += (double)o.x * (double)o.x + (double)o.y * (double)o.y;
+                    else acc += ((double)o.x * (double)o.x + (double)o.y * (double)o.y) +
+                                ((double)o.z * (double)o.z + (double)o.w * (double)o.w);
+                }
+                if constexpr (MODE == 2 && W == 2) {
+                    float2 f = make_float2((float)(o.x * inv_scale), (float)(o.y * inv_scale));
+                    if (c.st) *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + c.col + (long)r * pitch_out) = f;
+                }
+            }
+            up = cur; cur = dn;
+        }
+    }
+    if (MODE != 0) {
+        // wave shuffle reduction -> LDS -> one partial per block (deterministic:
+        // no atomics, the final sum is a fixed-order second kernel)
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int w = 0; w < kWavesPerBlock; ++w) s += wsum[w];
+            partial[blockIdx.x] = s;
+        }
+    }
+}
+
+// fixed-order final reduction of the per-block partials: out[0] = sum
+__global__ void __launch_bounds__(kBlock) k_reduce_partials(const double* __restrict__ partial, int n, double* __restrict__ out)
+{
+    __shared__ double wsum[kWavesPerBlock];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += kBlock) acc += partial[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < kWavesPerBlock; ++w) s += wsum[w];
+        out[0] = s;
+    }
+}
+
+// =============================================================================
+// restriction (PS:531-546 index pattern):  coarse(I,J) = w * (corners + 2 edges
+// + 4 centre) centred on fine (2I, 2J), in the reference's summation order.
+// FUSED: the fine field is the residual of (v, b), computed on the fly and never
+// written (reads v + b, writes the coarse RHS: 2 + 1/4 values per fine point).
+// !FUSED: the fine field is `rhs` itself (FMG right-hand sides, PS:641).
+// ZERO_GUESS: also zero-fill the coarse solution array (PS:613) while here.
+// A lane owns fine columns [col, col+W): W/2 coarse columns col/2 ...
+// Coarse rows [crow_lo, crow_hi) are produced; fine local row of coarse local
+// row I is 2*I + fine_row_off (0 on a single GPU; slab offset otherwise).
+// =============================================================================
+template <typename T> struct Trip { T l, c, r; };   // residual left / centre / right of a coarse column
+
+template <typename T, bool FUSED>
+__global__ void __launch_bounds__(kBlock)
+k_restrict(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ coarse, T* __restrict__ coarse_zero,
+           int N, long pitch, long cpitch, int crow_lo, int crow_hi, int fine_row_off,
+           int R, int strips, int chunks, T wgt)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int W = VecOf<T>::W;
+    constexpr int CW = W / 2;               // coarse columns per lane
+    const Tile t = wave_tile(strips, chunks);
+    if (!t.active) return;
+    const Cols c = lane_cols<W>(t.strip, N, pitch);
+    const int I0 = crow_lo + t.chunk * R;
+    const int I1 = min(I0 + R, crow_hi);
+    const T* pv = vin + c.col;
+    const T* pb = rhs + c.col;
+    const long ccol = c.col / 2;
+    const int NC = N / 2;
+
+    // field row y (residual or plain), masked to the unknown columns
+    auto row_plain = [&](int y) -> V { V o = vload<V>(pb + (long)y * pitch, c.ld); mask_cols(o, c.col, N); return o; };
+
+    V up, cur, dn;          // v rows y-1, y, y+1 (FUSED only)
+    int yf = 2 * I0 + fine_row_off - 1;     // first field row needed: 2*I0 - 1
+    if (FUSED) {
+        up = vload<V>(pv + (long)(yf - 1) * pitch, c.ld);
+        cur = vload<V>(pv + (long)yf * pitch, c.ld);
+    }
+    auto next_field = [&](int y) -> V {
+        if (FUSED) {
+            dn = vload<V>(pv + (long)(y + 1) * pitch, c.ld);
+            const V bb = vload<V>(pb + (long)y * pitch, c.ld);
+            V o = residual_vec(up, cur, dn, bb);
+            mask_cols(o, c.col, N);
+            up = cur; cur = dn;
+            return o;
+        } else {
+            return row_plain(y);
+        }
+    };
+    // horizontal neighbours of the coarse columns this lane owns
+    auto trips = [&](const V& f, Trip<T>* tr) {
+        const T l = from_left(last(f));
+        if constexpr (W == 2) { tr[0] = {l, f.x, f.y}; }
+        else { tr[0] = {l, f.x, f.y}; tr[1] = {f.y, f.z, f.w}; }
+    };
+
+    Trip<T> top[CW], mid[CW], bot[CW];
+    { const V f = next_field(yf); trips(f, top); }
+    for (int I = I0; I < I1; ++I) {
+        const int y = 2 * I + fine_row_off;
+        { const V f = next_field(y); trips(f, mid); }
+        { const V f = next_field(y + 1); trips(f, bot); }
+        T o[CW];
+#pragma unroll
+        for (int k = 0; k < CW; ++k) {
+            // PS:539-542 order: ((nw+ne)+sw)+se + 2*(((w+e)+n)+s) + 4*c
+            T corners = top[k].l + top[k].r; corners = corners + bot[k].l; corners = corners + bot[k].r;
+            T edges = mid[k].l + mid[k].r; edges = edges + top[k].c; edges = edges + bot[k].c;
+            o[k] = wgt * ((corners + (T)2 * edges) + (T)4 * mid[k].c);
+            if (ccol + k == 0 || ccol + k >= NC) o[k] = (T)0;
+        }
+        if (c.st) {
+            T* pc = coarse + (long)I * cpitch + ccol;
+            if constexpr (CW == 1) { pc[0] = o[0]; }
+            else { *reinterpret_cast<float2*>(pc) = make_float2((float)o[0], (float)o[1]); }
+            if (coarse_zero) {
+                T* pz = coarse_zero + (long)I * cpitch + ccol;
+                if constexpr (CW == 1) { pz[0] = (T)0; }
+                else { *reinterpret_cast<float2*>(pz) = make_float2(0.f, 0.f); }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CW; ++k) top[k] = bot[k];
+    }
+}
+
+// =============================================================================
+// bilinear prolongation (PS:337-425) with the coarse-grid correction add
+// (PS:620-624) fused:  ADD: v += P e  (in place);  !ADD: v = P e  (FMG, PS:645).
+// A lane owns fine columns [col, col+W) of fine rows [row_lo,row_hi); coarse
+// values e(I, col/2 .. col/2 + W/2) come straight from the coarse array, whose
+// own zero ring supplies the reference's boundary special cases (PS:341-390).
+// Fine local row y maps to coarse local row (y - fine_row_off)/2.
+// =============================================================================
+template <typename T, bool ADD>
+__global__ void __launch_bounds__(kBlock)
+k_prolong(T* __restrict__ v, const T* __restrict__ coarse, int N, long pitch, long cpitch,
+          int row_lo, int row_hi, int fine_row_off, int R, int strips, int chunks)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int W = VecOf<T>::W;
+    constexpr int CW = W / 2;
+    const Tile t = wave_tile(strips, chunks);
+    if (!t.active) return;
+    const Cols c = lane_cols<W>(t.strip, N, pitch);
+    const int r0 = row_lo + t.chunk * R;
+    const int r1 = min(r0 + R, row_hi);
+    T* pv = v + c.col;
+    const long ccol = c.col / 2;
+    const bool cld = c.ld && (ccol + CW < cpitch);
+
+    // coarse row I: values at coarse columns ccol .. ccol+CW (CW+1 of them)
+    auto crow = [&](int I, T* e) {
+        const T* p = coarse + (long)I * cpitch + ccol;
+#pragma unroll
+        for (int k = 0; k <= CW; ++k) e[k] = cld ? p[k] : (T)0;
+    };
+    for (int r = r0; r < r1; ++r) {
+        const int y = r - fine_row_off;
+        const int I = y >> 1;
+        T a[CW + 1], b2[CW + 1];
+        crow(I, a);
+        V add;
+        T o[W];
+        if ((y & 1) == 0) {             // PS:398-402, 410-414
+#pragma unroll
+            for (int k = 0; k < CW; ++k) { o[2 * k] = a[k]; o[2 * k + 1] = (T)0.5 * (a[k] + a[k + 1]); }
+        } else {                        // PS:404-408, 416-420: ((NW + SW) + NE) + SE
+            crow(I + 1, b2);
+#pragma unroll
+            for (int k = 0; k < CW; ++k) {
+                o[2 * k] = (T)0.5 * (a[k] + b2[k]);
+                o[2 * k + 1] = (T)0.25 * (((a[k] + b2[k]) + a[k + 1]) + b2[k + 1]);
+            }
+        }
+        if constexpr (W == 2) add = make_double2(o[0], o[1]);
+        else add = make_float4(o[0], o[1], o[2], o[3]);
+        mask_cols(add, c.col, N);
+        if (ADD) {
+            const V old = vload<V>(pv + (long)r * pitch, c.st);
+            if constexpr (W == 2) { add.x = old.x + add.x; add.y = old.y + add.y; }
+            else { add.x = old.x + add.x; add.y = old.y + add.y; add.z = old.z + add.z; add.w = old.w + add.w; }
+        }
+        vstore<V>(pv + (long)r * pitch, add, c.st);
+    }
+}
+
+// mixed precision (config 5): u64 += scale * (double) e32, rows [row_lo,row_hi)
+__global__ void __launch_bounds__(kBlock)
+k_axpy_f32_to_f64(double* __restrict__ u, const float* __restrict__ e, double scale, int N, long pitch, long epitch,
+                  int row_lo, int row_hi, int R, int strips, int chunks, int assign)
+{
+    const Tile t = wave_tile(strips, chunks);
+    if (!t.active) return;
+    const Cols c = lane_cols<2>(t.strip, N, pitch);
+    const int r0 = row_lo + t.chunk * R;
+    const int r1 = min(r0 + R, row_hi);
+    for (int r = r0; r < r1; ++r) {
+        if (c.st) {
+            const float2 ev = *reinterpret_cast<const float2*>(e + (long)r * epitch + c.col);
+            double2* pu = reinterpret_cast<double2*>(u + (long)r * pitch + c.col);
+            double2 o = assign ? make_double2(0.0, 0.0) : *pu;
+            o.x = o.x + scale * (double)ev.x;
+            o.y = o.y + scale * (double)ev.y;
+            if (c.col == 0) o.x = 0.0;
+            *pu = o;
+        }
+    }
+}
+
+// f64 grid -> f32 grid with scaling (mixed FMG right-hand side)
+__global__ void __launch_bounds__(kBlock)
+k_scale_f64_to_f32(float* __restrict__ out, const double* __restrict__ in, double inv_scale, int N, long pitch_in, long pitch_out,
+                   int row_lo, int row_hi, int R, int strips, int chunks)
+{
+    const Tile t = wave_tile(strips, chunks);
+    if (!t.active) return;
+    const Cols c = lane_cols<2>(t.strip, N, pitch_in);
+    const int r0 = row_lo + t.chunk * R;
+    const int r1 = min(r0 + R, row_hi);
+    for (int r = r0; r < r1; ++r) {
+        if (c.st) {
+            double2 x = *reinterpret_cast<const double2*>(in + (long)r * pitch_in + c.col);
+            if (c.col == 0) x.x = 0.0;
+            *reinterpret_cast<float2*>(out + (long)r * pitch_out + c.col) =
+                make_float2((float)(x.x * inv_scale), (float)(x.y * inv_scale));
+        }
+    }
+}
+
+// =============================================================================
+// launch geometry
+// =============================================================================
+struct Launch { int R, strips, chunks, blocks; };
+
+// rows: number of rows to process; W: elements per vector; rows_per_chunk <= 0 = auto
+inline Launch make_launch(int N, int W, int rows, int rows_per_chunk)
+{
+    Launch L;
+    const int nvec_out = N / W;
+    L.strips = (nvec_out + kOutLanes - 1) / kOutLanes;
+    if (L.strips < 1) L.strips = 1;
+    int R = rows_per_chunk;
+    if (R <= 0) {
+        // enough waves to fill 256 CUs several times over, long enough chunks
+        // that the halo-row re-read (served by L2) stays a few percent
+        R = rows / 128;
+        if (R < 4) R = 4;
+        if (R > 32) R = 32;
+    }
+    L.R = R;
+    L.chunks = (rows + R - 1) / R;
+    if (L.chunks < 1) L.chunks = 1;
+    const long waves = (long)L.strips * L.chunks;
+    long blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    blocks = (blocks + 7) / 8 * 8;
+    L.blocks = (int)blocks;
+    return L;
+}
+
+} // namespace mgx

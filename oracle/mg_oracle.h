@@ -1,0 +1,126 @@
+/*
+ * mg_oracle.h — CPU oracle for the 2-D Poisson geometric-multigrid hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / reported CPU baseline.
+ *
+ * PARITY UNPINNED.  The reference (nikhilTkur/Multigrid_Nikhil_C-) ships no
+ * tests, fixtures or golden vectors, and it cannot be built here: it needs
+ * <CL/sycl.hpp>, oneMKL and Eigen, none of which exist in this image, and no
+ * stand-ins are written for them.  This file is therefore a plain-C
+ * restatement of the reference's *intended* algorithm; every place where the
+ * restatement departs from the literal text is a row of SURVEY.md §2.3
+ * (D1..D12) and is called out next to the function it affects.
+ *
+ * Citations: PS = /root/reference/Poissons_SYCL.cpp,
+ *            MF = /root/reference/Multigrid_functions.cpp.
+ *
+ * Layout: every vector is the reference's interior-only row-major n x n array
+ * (PS:227-233, PS:291), n = 2^L - 1, element (i,j) 0-based at i*n + j is grid
+ * node (row i+1, col j+1) of the (2^L+1)^2 node mesh; the Dirichlet ring is
+ * implicit and zero.  Operator: SPD form A = [-1; -1 4 -1; -1], b = h^2 f (D1).
+ */
+#ifndef MG_ORACLE_H
+#define MG_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_SMOOTHER_JACOBI = 0, ORC_SMOOTHER_RBGS = 1 };
+enum { ORC_DTYPE_F32 = 0, ORC_DTYPE_F64 = 1, ORC_DTYPE_MIXED = 2 };
+enum { ORC_SCHEDULE_V = 0, ORC_SCHEDULE_FMG = 1 };
+enum { ORC_RESTRICT_CONSISTENT = 0, ORC_RESTRICT_FW16 = 1 };
+enum { ORC_BOTTOM_EXACT = 0, ORC_BOTTOM_SMOOTH = 1 };
+
+/* Mirrors the reference's compile-time globals (PS:17-22, PS:127) as run-time
+ * fields; same field order as mgx_config in include/mgx.h. */
+typedef struct {
+    int finest_level;    /* PS:17 (10) */
+    int coarsest_level;  /* PS:18 (7)  */
+    int mu0;             /* PS:20: FMG runs mu0+1 V-cycles per level (PS:646) */
+    int mu1;             /* PS:21 pre-smoothing sweeps */
+    int mu2;             /* PS:22 post-smoothing sweeps */
+    double omega;        /* PS:127 (2/3) */
+    int smoother;        /* ORC_SMOOTHER_* */
+    int dtype;           /* ORC_DTYPE_* */
+    int schedule;        /* ORC_SCHEDULE_* */
+    int restrict_mode;   /* ORC_RESTRICT_* (D4) */
+    int bottom;          /* ORC_BOTTOM_* (D8) */
+} orc_config;
+
+void orc_config_default(orc_config* c);
+
+/* ---- grid operators (f64 / f32) ------------------------------------- */
+/* PS:125-147 weighted Jacobi, mu sweeps, in place (uses an internal copy). */
+void orc_jacobi_f64(double* v, const double* f, int n, int mu, double omega);
+void orc_jacobi_f32(float* v, const float* f, int n, int mu, double omega);
+/* red-black Gauss-Seidel (absent from the reference). */
+void orc_rbgs_f64(double* v, const double* f, int n, int mu);
+void orc_rbgs_f32(float* v, const float* f, int n, int mu);
+/* PS:604-607 residual r = f - (LU v + D v). */
+void orc_residual_f64(double* r, const double* v, const double* f, int n);
+void orc_residual_f32(float* r, const float* v, const float* f, int n);
+/* PS:531-546 restriction; nf fine interior size, coarse is (nf-1)/2. */
+void orc_restrict_f64(double* coarse, const double* fine, int nf, int mode);
+void orc_restrict_f32(float* coarse, const float* fine, int nf, int mode);
+/* PS:337-425 bilinear interpolation; fine is (2 nc + 1)^2. */
+void orc_prolong_f64(double* fine, const double* coarse, int nc);
+void orc_prolong_f32(float* fine, const float* coarse, int nc);
+/* PS:620-624: v <- v + P e. */
+void orc_prolong_add_f64(double* v, const double* coarse, int nc);
+void orc_prolong_add_f32(float* v, const float* coarse, int nc);
+double orc_norm2_f64(const double* x, size_t len);
+double orc_norm2_f32(const float* x, size_t len);
+
+/* ---- solver ---------------------------------------------------------- */
+typedef struct orc_solver orc_solver;
+orc_solver* orc_create(const orc_config* cfg);
+void orc_destroy(orc_solver* s);
+
+/* exact bottom solve A x = rhs on the coarsest level (MF:63-72, MF:137-139):
+ * banded Cholesky in double. */
+void orc_bottom_solve_f64(orc_solver* s, double* x, const double* rhs);
+void orc_bottom_solve_f32(orc_solver* s, float* x, const float* rhs);
+
+/* PS:575-627 / MF:132-173: one V-cycle at `level`, v updated in place. */
+void orc_vcycle_f64(orc_solver* s, int level, double* v, const double* f);
+void orc_vcycle_f32(orc_solver* s, int level, float* v, const float* f);
+/* PS:629-650 / MF:175-191: full multigrid from `level`; v is output. */
+void orc_fmg_f64(orc_solver* s, int level, double* v, const double* f);
+void orc_fmg_f32(orc_solver* s, int level, float* v, const float* f);
+
+/* Whole solve (PS:727 entry point + the residual report D10 asks for).
+ * u: in = initial guess, out = solution (finest level, n^2 values, double for
+ * f64/mixed, and also double-typed storage for f32: values are float-rounded).
+ * hist[0] = ||b - A u0||_2, hist[k] = after cycle k.  Returns cycles run.
+ * Stops when hist[k] <= tol * hist[0] or k == max_cycles. */
+int orc_solve(orc_solver* s, const double* b, double* u, double tol,
+              int max_cycles, double* hist);
+
+/* ---- problem data ---------------------------------------------------- */
+/* RHS-A: PS:283-335 load vector in SPD sign (D1): b = f h^2, f = 4 (PS:123). */
+void orc_rhs_constant(double* b, int level, double f);
+/* RHS-B: b = h^2 8 pi^2 sin(2 pi x) sin(2 pi y). */
+void orc_rhs_sine(double* b, int level);
+/* u0 ~ U(-1,1): x = mt19937_64(seed), u = (x >> 11) * 2^-52 - 1. */
+void orc_fill_uniform(double* u, size_t len, uint64_t seed);
+
+/* ---- CPU baselines -------------------------------------- */
+/* flavour 1 "reference-shaped": CSR SpMV + scal + scal + add + add + copy per
+ * sweep exactly as PS:137-145, one thread.  Returns seconds for `mu` sweeps. */
+double orc_baseline_csr_jacobi_f32(float* v, const float* f, int n, int mu, double omega);
+double orc_baseline_csr_jacobi_f64(double* v, const double* f, int n, int mu, double omega);
+/* flavour 2 "best-effort": matrix-free stencil, OpenMP over rows. */
+double orc_baseline_omp_jacobi_f64(double* v, const double* f, int n, int mu, double omega, int threads);
+double orc_baseline_omp_jacobi_f32(float* v, const float* f, int n, int mu, double omega, int threads);
+int orc_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,89 @@
+"""CPU checks of the drop-in boundary: libmgx.so loads, exports every symbol
+include/mgx.h declares, and refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, have_gpu
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mgx.h")).read()
+    return sorted(set(re.findall(r"MGX_API\s+[\w\s\*]+?\b(mgx_\w+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(pkg):
+    declared = _declared_symbols()
+    assert declared, "no MGX_API declarations found"
+    assert sorted(pkg.EXPORTS) == declared
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    for name in _declared_symbols():
+        assert hasattr(L, name), f"libmgx.so does not export {name}"
+
+
+def test_only_the_c_abi_is_exported(pkg):
+    # -fvisibility=hidden: nothing but the mgx_* C symbols leaves the library
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if " T " in ln]
+    assert names and all(n.startswith("mgx_") for n in names), names
+
+
+def test_struct_layouts_match_the_header(pkg, tmp_path):
+    # ask the C compiler what include/mgx.h lays out and compare with ctypes
+    import subprocess
+
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "mgx.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mgx_config), offsetof(mgx_config, omega),'
+        ' offsetof(mgx_config, profile), sizeof(mgx_stats), offsetof(mgx_stats, fine_updates),'
+        ' sizeof(mgx_profile), sizeof(mgx_slab)); return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    from multigrid_nikhil_c_amd import binding as B
+
+    assert got == [C.sizeof(B.Config), B.Config.omega.offset, B.Config.profile.offset, C.sizeof(B.Stats),
+                   B.Stats.fine_updates.offset, C.sizeof(B.Profile), C.sizeof(B.Slab)]
+
+
+def test_defaults_are_the_reference_globals(pkg):
+    c = pkg.default_config()
+    # PS:17-22, PS:127
+    assert (c.finest_level, c.coarsest_level, c.mu0, c.mu1, c.mu2) == (10, 7, 30, 10, 10)
+    assert c.omega == 2.0 / 3.0
+    assert c.schedule == pkg.SCHEDULE_FMG and c.smoother == pkg.SMOOTHER_JACOBI
+
+
+def test_geometry_helpers(pkg):
+    L = pkg.lib()
+    assert L.mgx_level_n(10) == 1023 and L.mgx_level_n(7) == 127     # PS:662-664
+    # rows are 256-byte multiples and hold columns 0..N
+    for lvl in (2, 5, 7, 13):
+        for dt, es in ((pkg.DTYPE_F32, 4), (pkg.DTYPE_F64, 8)):
+            p = L.mgx_level_pitch(lvl, dt)
+            assert p >= (1 << lvl) + 1 and (p * es) % 256 == 0
+    assert L.mgx_level_pitch(0, pkg.DTYPE_F64) == -1
+
+
+def test_invalid_configs_are_rejected(pkg):
+    for bad in (dict(finest_level=5, coarsest_level=6), dict(coarsest_level=1), dict(omega=0.0),
+                dict(dtype=7), dict(finest_level=12, coarsest_level=9)):
+        with pytest.raises(pkg.MgxError):
+            pkg.Multigrid(**bad)
+
+
+@pytest.mark.skipif(have_gpu(), reason="a GPU is present")
+def test_no_cpu_fallback(pkg):
+    with pytest.raises(pkg.MgxError, match="no usable HIP device"):
+        pkg.Multigrid()
+    # slab operators validate their arguments before touching the device
+    s = pkg.Slab(level=1, dtype=pkg.DTYPE_F64, rows=4, row0=0)
+    assert pkg.lib().mgx_slab_scratch_doubles(C.byref(s)) == -1

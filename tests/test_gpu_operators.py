@@ -1,0 +1,179 @@
+"""GPU parity, operator by operator: the HIP kernels behind the C-ABI against
+the CPU oracle on the same seeded inputs, and against the committed fixtures.
+Tolerances: fp64 <= 1e-12 * max|.| per operator application (the
+device contracts a*b+c into FMA, the oracle does not: last-ulp differences);
+fp32 <= 4 ulp * max|.| per sweep."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+F32_ULP = float(np.finfo(np.float32).eps)
+
+DT = {
+    "f64": (np.float64, 1, 1e-12),
+    "f32": (np.float32, 0, 4 * F32_ULP),
+}
+
+
+def close(a, b, tol, scale=None):
+    s = np.max(np.abs(b)) if scale is None else scale
+    return np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))) <= tol * max(s, 1e-300)
+
+
+@pytest.fixture(scope="module")
+def mgs(pkg):
+    """one handle per (dtype, smoother) spanning levels 2..10"""
+    hs = {}
+    for name, (dt, code, _) in DT.items():
+        for sm in (0, 1):
+            hs[(name, sm)] = pkg.Multigrid(finest_level=10, coarsest_level=2, dtype=code, smoother=sm,
+                                           bottom=pkg.BOTTOM_SMOOTH)
+    yield hs
+    for h in hs.values():
+        h.close()
+
+
+@pytest.mark.parametrize("name", ["f64", "f32"])
+@pytest.mark.parametrize("level", [2, 3, 5, 6, 7, 8, 10])
+def test_jacobi_matches_oracle(mgs, po, name, level):
+    dt, _, tol = DT[name]
+    n = (1 << level) - 1
+    rng = np.random.default_rng(100 + level)
+    v = rng.uniform(-1, 1, (n, n)).astype(dt)
+    f = rng.uniform(-1, 1, (n, n)).astype(dt)
+    for mu in (1, 2, 5):
+        got = mgs[(name, 0)].jacobirelaxation(level, v, f, mu)
+        assert close(got, po.jacobi(v, f, mu), tol * mu), (name, level, mu)
+
+
+@pytest.mark.parametrize("name", ["f64", "f32"])
+@pytest.mark.parametrize("level", [2, 3, 5, 6, 7, 8, 10])
+def test_rbgs_matches_oracle(mgs, po, name, level):
+    dt, _, tol = DT[name]
+    n = (1 << level) - 1
+    rng = np.random.default_rng(200 + level)
+    v = rng.uniform(-1, 1, (n, n)).astype(dt)
+    f = rng.uniform(-1, 1, (n, n)).astype(dt)
+    for mu in (1, 2, 3):
+        got = mgs[(name, 1)].jacobirelaxation(level, v, f, mu)
+        assert close(got, po.rbgs(v, f, mu), 2 * tol * mu), (name, level, mu)
+
+
+@pytest.mark.parametrize("name", ["f64", "f32"])
+@pytest.mark.parametrize("level", [2, 3, 6, 7, 9, 10])
+def test_residual_matches_oracle(mgs, po, name, level):
+    dt, _, tol = DT[name]
+    n = (1 << level) - 1
+    rng = np.random.default_rng(300 + level)
+    v = rng.uniform(-1, 1, (n, n)).astype(dt)
+    f = rng.uniform(-1, 1, (n, n)).astype(dt)
+    got = mgs[(name, 0)].residual(level, v, f)
+    assert close(got, po.residual(v, f), 2 * tol, scale=8.0)
+    # and its norm
+    mg = mgs[(name, 0)]
+    mg.set_level(level, 0, v)
+    mg.set_level(level, 1, f)
+    assert abs(mg.residual_norm(level) - po.norm2(po.residual(v, f))) <= (1e-12 if name == "f64" else 1e-5) * po.norm2(po.residual(v, f))
+
+
+@pytest.mark.parametrize("name", ["f64", "f32"])
+@pytest.mark.parametrize("level", [3, 4, 6, 7, 9, 10])
+def test_restriction_and_fused_residual_restriction(mgs, po, name, level):
+    dt, _, tol = DT[name]
+    n = (1 << level) - 1
+    rng = np.random.default_rng(400 + level)
+    v = rng.uniform(-1, 1, (n, n)).astype(dt)
+    f = rng.uniform(-1, 1, (n, n)).astype(dt)
+    mg = mgs[(name, 0)]
+    assert close(mg.restriction2d(level, f), po.restrict(f), tol, scale=4.0)
+    cb, cu = mg.residual_restriction(level, v, f)
+    assert close(cb, po.restrict(po.residual(v, f)), 4 * tol, scale=32.0)
+    assert np.all(cu == 0)          # PS:613: the coarse guess is zeroed in the same pass
+
+
+@pytest.mark.parametrize("name", ["f64", "f32"])
+@pytest.mark.parametrize("level", [3, 4, 6, 7, 9, 10])
+def test_prolongation_matches_oracle(mgs, po, name, level):
+    dt, _, tol = DT[name]
+    n, nc = (1 << level) - 1, (1 << (level - 1)) - 1
+    rng = np.random.default_rng(500 + level)
+    v = rng.uniform(-1, 1, (n, n)).astype(dt)
+    e = rng.uniform(-1, 1, (nc, nc)).astype(dt)
+    mg = mgs[(name, 0)]
+    # bilinear weights are exact binary fractions: the only rounding is the sums
+    assert close(mg.interpolation2d(level, e), po.prolong(e), tol)
+    assert close(mg.interpolation_add(level, v, e), po.prolong_add(v, e), tol)
+
+
+def test_survey_pin_prolongation_of_ones_on_device(mgs):
+    p = mgs[("f64", 0)].interpolation2d(3, np.ones((3, 3)))
+    assert np.all(p[1:-1, 1:-1] == 1.0) and p[0, 0] == 0.25 and np.all(p[0, 1:-1] == 0.5)
+
+
+def test_restriction_weight_modes(pkg, po):
+    rng = np.random.default_rng(7)
+    f = rng.uniform(-1, 1, (63, 63))
+    with pkg.Multigrid(finest_level=6, coarsest_level=5, restrict_mode=pkg.RESTRICT_FW16) as mg:
+        assert close(mg.restriction2d(6, f), po.restrict(f, po.RESTRICT_FW16), 1e-13, scale=1.0)
+
+
+@pytest.mark.parametrize("level", [2, 5, 6, 7, 8])
+@pytest.mark.parametrize("name", ["f64", "f32"])
+def test_exact_bottom_solve(pkg, po, level, name):
+    dt, code, _ = DT[name]
+    n = (1 << level) - 1
+    rng = np.random.default_rng(600 + level)
+    u = rng.uniform(-1, 1, (n, n))
+    f = (4 * u - (np.pad(u, 1)[:-2, 1:-1] + np.pad(u, 1)[2:, 1:-1] + np.pad(u, 1)[1:-1, :-2] + np.pad(u, 1)[1:-1, 2:]))
+    with pkg.Multigrid(finest_level=level, coarsest_level=level, dtype=code) as mg:
+        x = mg.bottom_solve(f.astype(dt))
+    ref = po.Solver(finest_level=level, coarsest_level=level).bottom_solve(f.astype(dt).astype(np.float64))
+    assert close(x, ref, 1e-11 if name == "f64" else 2 * F32_ULP)
+    if name == "f64":
+        assert close(x, u, 1e-11)
+
+
+@pytest.mark.parametrize("level", [5, 6])
+def test_device_matches_committed_fixtures(mgs, level):
+    g = np.load(os.path.join(GOLD, f"operators_L{level}.npz"))
+    for name, (dt, _, tol) in DT.items():
+        v, f, e = g["v"].astype(dt), g["f"].astype(dt), g["e"].astype(dt)
+        mj, mr = mgs[(name, 0)], mgs[(name, 1)]
+        assert close(mj.jacobirelaxation(level, v, f, 3), g[f"jacobi3_{name}"], 3 * tol)
+        assert close(mr.jacobirelaxation(level, v, f, 2), g[f"rbgs2_{name}"], 4 * tol)
+        assert close(mj.residual(level, v, f), g[f"residual_{name}"], 2 * tol, scale=8.0)
+        assert close(mj.restriction2d(level, f), g[f"restrict_{name}"], tol, scale=4.0)
+        assert close(mj.residual_restriction(level, v, f)[0], g[f"resrestrict_{name}"], 4 * tol, scale=32.0)
+        assert close(mj.interpolation2d(level, e), g[f"prolong_{name}"], tol)
+        assert close(mj.interpolation_add(level, v, e), g[f"prolong_add_{name}"], tol)
+
+
+def test_boundary_ring_and_padding_stay_zero(pkg):
+    """edge case: data that is largest next to the Dirichlet ring; smoothing must
+    treat the ring as exact zeros on every side (PS:188-198, 224)."""
+    rng = np.random.default_rng(8)
+    n = 31
+    v = np.zeros((n, n)); f = np.zeros((n, n))
+    v[0, :] = v[-1, :] = v[:, 0] = v[:, -1] = 1.0
+    with pkg.Multigrid(finest_level=5, coarsest_level=4) as mg:
+        out = mg.jacobirelaxation(5, v, f, 1)
+    # corner: (1-w)*1 + (w/4)*(two ring zeros + two ones)
+    w = 2.0 / 3.0
+    assert abs(out[0, 0] - ((1 - w) + (w / 4) * 2)) < 1e-15
+    assert abs(out[0, 5] - ((1 - w) + (w / 4) * 2)) < 1e-15
+    assert abs(out[1, 1] - ((w / 4) * 2)) < 1e-15
+
+
+def test_smoother_is_linear_and_zero_preserving(mgs):
+    rng = np.random.default_rng(9)
+    n = 255
+    v = rng.uniform(-1, 1, (n, n)); f = rng.uniform(-1, 1, (n, n))
+    mg = mgs[("f64", 0)]
+    a = mg.jacobirelaxation(8, v, f, 2)
+    b = mg.jacobirelaxation(8, 2 * v, 2 * f, 2)
+    assert np.array_equal(b, 2 * a)           # scaling by 2 is exact in binary
+    assert np.all(mg.jacobirelaxation(8, 0 * v, 0 * f, 3) == 0)

@@ -1,0 +1,140 @@
+"""GPU checks of the slab-level C-ABI (what the multi-GPU driver composes):
+operators applied slab by slab, with explicit halo rows, must reproduce the
+whole-grid result bit for bit (same kernels, same arithmetic)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def grid_from_interior(pkg, a, level, dt):
+    """padded device grid (rows 0..N, level pitch) from an interior array"""
+    torch = _torch()
+    N = 1 << level
+    pitch = pkg.lib().mgx_level_pitch(level, pkg.DTYPE_F64 if dt == np.float64 else pkg.DTYPE_F32)
+    g = np.zeros((N + 1, pitch), dtype=dt)
+    g[1:N, 1:N] = a
+    return torch.from_numpy(g).cuda()
+
+
+def interior(t, level):
+    N = 1 << level
+    return t.cpu().numpy()[1:N, 1:N]
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("smoother", ["jacobi", "rbgs"])
+def test_two_slabs_with_deep_halo_equal_whole_grid(pkg, po, dt, smoother):
+    torch = _torch()
+    L = pkg.lib()
+    level, mu = 7, 3
+    N = 1 << level
+    code = pkg.DTYPE_F64 if dt == np.float64 else pkg.DTYPE_F32
+    rng = np.random.default_rng(11)
+    v = rng.uniform(-1, 1, (N - 1, N - 1)).astype(dt)
+    f = rng.uniform(-1, 1, (N - 1, N - 1)).astype(dt)
+    U, B = grid_from_interior(pkg, v, level, dt), grid_from_interior(pkg, f, level, dt)
+    ref = po.rbgs(v, f, mu) if smoother == "rbgs" else po.jacobi(v, f, mu)
+    depth = 2 * mu if smoother == "rbgs" else mu
+    out = np.zeros_like(v)
+    half = N // 2
+    for rank, (own_lo, own_hi) in enumerate([(0, half), (half, N + 1)]):
+        lo = max(own_lo - depth, 0)
+        hi = min(own_hi + depth, N + 1)
+        u = U[lo:hi].clone(); b = B[lo:hi].clone(); tmp = torch.zeros_like(u)
+        s = pkg.Slab(level=level, dtype=code, rows=hi - lo, row0=lo)
+        flag = C.c_int()
+        rl, rh = max(own_lo, 1) - lo, min(own_hi, N) - lo
+        if smoother == "rbgs":
+            st = L.mgx_slab_rbgs(C.byref(s), u.data_ptr(), b.data_ptr(), tmp.data_ptr(), rl, rh, mu, 1, C.byref(flag), None)
+        else:
+            st = L.mgx_slab_jacobi(C.byref(s), u.data_ptr(), b.data_ptr(), tmp.data_ptr(), rl, rh, mu, 2.0 / 3.0, 1, C.byref(flag), None)
+        assert st == 0
+        torch.cuda.synchronize()
+        res = (tmp if flag.value else u).cpu().numpy()
+        out[max(own_lo, 1) - 1: min(own_hi, N) - 1] = res[rl:rh, 1:N]
+    tol = 1e-12 if dt == np.float64 else 1e-5
+    assert np.max(np.abs(out - ref)) <= tol
+    # and identical to the single-slab call (bitwise: same kernels)
+    u = U.clone(); tmp = torch.zeros_like(u)
+    s = pkg.Slab(level=level, dtype=code, rows=N + 1, row0=0)
+    flag = C.c_int()
+    if smoother == "rbgs":
+        assert L.mgx_slab_rbgs(C.byref(s), u.data_ptr(), B.data_ptr(), tmp.data_ptr(), 1, N, mu, 0, C.byref(flag), None) == 0
+    else:
+        assert L.mgx_slab_jacobi(C.byref(s), u.data_ptr(), B.data_ptr(), tmp.data_ptr(), 1, N, mu, 2.0 / 3.0, 0, C.byref(flag), None) == 0
+    torch.cuda.synchronize()
+    whole = interior(tmp if flag.value else u, level)
+    assert np.array_equal(out, whole)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_slab_restrict_prolong_and_norm(pkg, po, dt):
+    torch = _torch()
+    L = pkg.lib()
+    level = 7
+    N, NC = 1 << level, 1 << (level - 1)
+    code = pkg.DTYPE_F64 if dt == np.float64 else pkg.DTYPE_F32
+    rng = np.random.default_rng(12)
+    v = rng.uniform(-1, 1, (N - 1, N - 1)).astype(dt)
+    f = rng.uniform(-1, 1, (N - 1, N - 1)).astype(dt)
+    e = rng.uniform(-1, 1, (NC - 1, NC - 1)).astype(dt)
+    U, B, E = grid_from_interior(pkg, v, level, dt), grid_from_interior(pkg, f, level, dt), grid_from_interior(pkg, e, level - 1, dt)
+    tol = 1e-12 if dt == np.float64 else 2e-5
+    # restriction of the residual, coarse rows split 16 | rest, fine slabs with 2-row halos
+    ref_c = po.restrict(po.residual(v, f))
+    got_c = np.zeros_like(ref_c)
+    for (c_lo, c_hi) in [(1, 17), (17, NC)]:
+        f_lo, f_hi = 2 * c_lo - 2, 2 * (c_hi - 1) + 3          # fine rows needed (exclusive hi)
+        fs = pkg.Slab(level=level, dtype=code, rows=f_hi - f_lo, row0=f_lo)
+        cs = pkg.Slab(level=level - 1, dtype=code, rows=c_hi - c_lo, row0=c_lo)
+        cb = torch.zeros((c_hi - c_lo, E.shape[1]), dtype=E.dtype, device="cuda")
+        cz = torch.ones_like(cb)
+        st = L.mgx_slab_restrict(C.byref(fs), U[f_lo:f_hi].contiguous().data_ptr(), B[f_lo:f_hi].contiguous().data_ptr(),
+                                 C.byref(cs), cb.data_ptr(), cz.data_ptr(), 0, c_hi - c_lo, 0, 1, None)
+        assert st == 0
+        torch.cuda.synchronize()
+        got_c[c_lo - 1: c_hi - 1] = cb.cpu().numpy()[:, 1:NC]
+        assert np.all(cz.cpu().numpy()[:, :NC] == 0)
+    assert np.max(np.abs(got_c - ref_c)) <= tol * 32
+    # prolongation + add on the lower half of the fine rows, coarse slab with one halo row
+    ref_p = po.prolong_add(v, e)
+    f_lo, f_hi = N // 2, N
+    c_lo, c_hi = f_lo // 2, NC + 1
+    fs = pkg.Slab(level=level, dtype=code, rows=f_hi - f_lo, row0=f_lo)
+    cs = pkg.Slab(level=level - 1, dtype=code, rows=c_hi - c_lo, row0=c_lo)
+    u = U[f_lo:f_hi].clone()
+    st = L.mgx_slab_prolong(C.byref(fs), u.data_ptr(), C.byref(cs), E[c_lo:c_hi].contiguous().data_ptr(), 0, f_hi - f_lo, 1, None)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert np.max(np.abs(u.cpu().numpy()[:, 1:N] - ref_p[f_lo - 1:])) <= tol
+    # residual sum of squares over a row range
+    s = pkg.Slab(level=level, dtype=code, rows=N + 1, row0=0)
+    scratch = torch.zeros(L.mgx_slab_scratch_doubles(C.byref(s)), dtype=torch.float64, device="cuda")
+    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    assert L.mgx_slab_residual_sumsq(C.byref(s), U.data_ptr(), B.data_ptr(), 10, 50, scratch.data_ptr(), out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    r = po.residual(v, f)[9:49].astype(np.float64)
+    assert abs(out.item() - np.sum(r * r)) <= (1e-12 if dt == np.float64 else 1e-5) * np.sum(r * r)
+
+
+def test_slab_argument_validation(pkg):
+    torch = _torch()
+    L = pkg.lib()
+    s = pkg.Slab(level=6, dtype=pkg.DTYPE_F64, rows=10, row0=20)
+    t = torch.zeros((10, L.mgx_level_pitch(6, pkg.DTYPE_F64)), dtype=torch.float64, device="cuda")
+    flag = C.c_int()
+    # row range whose halo rows fall outside the slab must be refused, not run
+    assert L.mgx_slab_jacobi(C.byref(s), t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 10, 1, 0.6, 0, C.byref(flag), None) != 0
+    assert L.mgx_slab_jacobi(C.byref(s), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 10, 1, 0.6, 0, C.byref(flag), None) != 0
+    assert L.mgx_slab_rbgs(C.byref(s), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 9, 1, 0, C.byref(flag), None) != 0
+    assert L.mgx_slab_jacobi(C.byref(s), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 9, 1, 0.6, 0, C.byref(flag), None) == 0
+    torch.cuda.synchronize()
