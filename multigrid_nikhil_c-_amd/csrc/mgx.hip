@@ -126,12 +126,19 @@ void launch_jacobi(const T* vin, const T* b, T* vout, int N, long pitch, int row
                    double omega, int rpc, hipStream_t st)
 {
     if (row_hi <= row_lo) return;
-    const Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, rpc);
     // PS:127, 138-140: the float path evaluates the scalars in double from the
     // float omega and narrows them
     const T om = (T)omega;
     const T c0 = (T)(1.0 - (double)om);
     const T c1 = (T)((double)om / 4.0);
+    if (rpc <= 0) {
+        // default: one wave per row and strip (see k_jacobi_rows)
+        const Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, 1);
+        hipLaunchKernelGGL((k_jacobi_rows<T>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
+                           row_lo, row_hi, g.strips, c0, c1);
+        return;
+    }
+    const Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, rpc);
     hipLaunchKernelGGL((k_jacobi<T>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
                        row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1);
 }

@@ -173,6 +173,32 @@ k_jacobi(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ v
     }
 }
 
+// Same sweep with no marching: one wave per (row, strip).  Every wave issues its
+// four loads at once and retires; the three reads of each v row (as north, centre
+// and south) are served by L2 because vertically adjacent waves are dispatched
+// back to back on the same XCD.  Measured faster than the marching form on
+// MI355X at every size (tools/microbench, DESIGN.md "Kernel choices").
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_jacobi_rows(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
+              int N, long pitch, int row_lo, int row_hi, int strips, T c0, T c1)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int W = VecOf<T>::W;
+    const Tile t = wave_tile(strips, row_hi - row_lo);
+    if (!t.active) return;
+    const Cols c = lane_cols<W>(t.strip, N, pitch);
+    const int r = row_lo + t.chunk;
+    const T* pv = vin + c.col + (long)r * pitch;
+    const V up = vload<V>(pv - pitch, c.ld);
+    const V cur = vload<V>(pv, c.ld);
+    const V dn = vload<V>(pv + pitch, c.ld);
+    const V bb = vload<V>(rhs + c.col + (long)r * pitch, c.ld);
+    V o = jacobi_vec<T>(up, cur, dn, bb, c0, c1);
+    if (c.vx == 0) o.x = (T)0;
+    vstore<V>(vout + c.col + (long)r * pitch, o, c.st);
+}
+
 // =============================================================================
 // red-black Gauss-Seidel, one full sweep (red then black), out of place in one
 // pass: vout = GS_black(GS_red(vin)).  Colour = parity of (global row + col),
@@ -586,11 +612,12 @@ inline Launch make_launch(int N, int W, int rows, int rows_per_chunk)
     if (L.strips < 1) L.strips = 1;
     int R = rows_per_chunk;
     if (R <= 0) {
-        // enough waves to fill 256 CUs several times over, long enough chunks
-        // that the halo-row re-read (served by L2) stays a few percent
+        // short chunks measured best on MI355X (tools/microbench): many more
+        // waves than the chip holds, so the tail is short; the halo-row
+        // re-reads are L2 hits.
         R = rows / 128;
         if (R < 4) R = 4;
-        if (R > 32) R = 32;
+        if (R > 8) R = 8;
     }
     L.R = R;
     L.chunks = (rows + R - 1) / R;

@@ -1,8 +1,13 @@
 """GPU parity, operator by operator: the HIP kernels behind the C-ABI against
 the CPU oracle on the same seeded inputs, and against the committed fixtures.
-Tolerances: fp64 <= 1e-12 * max|.| per operator application (the
-device contracts a*b+c into FMA, the oracle does not: last-ulp differences);
-fp32 <= 4 ulp * max|.| per sweep."""
+
+The kernels are compiled with -ffp-contract=off and perform the oracle's IEEE
+operations in the oracle's order, so every grid operator (Jacobi, RB-GS,
+residual, restriction, prolongation, correction) is required to be BIT-EXACT in
+both precisions.  Only two things are compared to a tolerance: the exact bottom
+solve (sine transform on the device, banded Cholesky in the oracle: two
+different exact methods, <= 1e-11 relative) and norms (different summation
+order, <= 1e-12 relative)."""
 import os
 
 import numpy as np
@@ -22,6 +27,11 @@ DT = {
 def close(a, b, tol, scale=None):
     s = np.max(np.abs(b)) if scale is None else scale
     return np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))) <= tol * max(s, 1e-300)
+
+
+def exact(a, b):
+    assert a.dtype == b.dtype and a.shape == b.shape
+    return np.array_equal(a, b)
 
 
 @pytest.fixture(scope="module")
@@ -47,7 +57,7 @@ def test_jacobi_matches_oracle(mgs, po, name, level):
     f = rng.uniform(-1, 1, (n, n)).astype(dt)
     for mu in (1, 2, 5):
         got = mgs[(name, 0)].jacobirelaxation(level, v, f, mu)
-        assert close(got, po.jacobi(v, f, mu), tol * mu), (name, level, mu)
+        assert exact(got, po.jacobi(v, f, mu)), (name, level, mu)
 
 
 @pytest.mark.parametrize("name", ["f64", "f32"])
@@ -60,7 +70,7 @@ def test_rbgs_matches_oracle(mgs, po, name, level):
     f = rng.uniform(-1, 1, (n, n)).astype(dt)
     for mu in (1, 2, 3):
         got = mgs[(name, 1)].jacobirelaxation(level, v, f, mu)
-        assert close(got, po.rbgs(v, f, mu), 2 * tol * mu), (name, level, mu)
+        assert exact(got, po.rbgs(v, f, mu)), (name, level, mu)
 
 
 @pytest.mark.parametrize("name", ["f64", "f32"])
@@ -72,7 +82,7 @@ def test_residual_matches_oracle(mgs, po, name, level):
     v = rng.uniform(-1, 1, (n, n)).astype(dt)
     f = rng.uniform(-1, 1, (n, n)).astype(dt)
     got = mgs[(name, 0)].residual(level, v, f)
-    assert close(got, po.residual(v, f), 2 * tol, scale=8.0)
+    assert exact(got, po.residual(v, f))
     # and its norm
     mg = mgs[(name, 0)]
     mg.set_level(level, 0, v)
@@ -89,9 +99,9 @@ def test_restriction_and_fused_residual_restriction(mgs, po, name, level):
     v = rng.uniform(-1, 1, (n, n)).astype(dt)
     f = rng.uniform(-1, 1, (n, n)).astype(dt)
     mg = mgs[(name, 0)]
-    assert close(mg.restriction2d(level, f), po.restrict(f), tol, scale=4.0)
+    assert exact(mg.restriction2d(level, f), po.restrict(f))
     cb, cu = mg.residual_restriction(level, v, f)
-    assert close(cb, po.restrict(po.residual(v, f)), 4 * tol, scale=32.0)
+    assert exact(cb, po.restrict(po.residual(v, f)))
     assert np.all(cu == 0)          # PS:613: the coarse guess is zeroed in the same pass
 
 
@@ -104,9 +114,8 @@ def test_prolongation_matches_oracle(mgs, po, name, level):
     v = rng.uniform(-1, 1, (n, n)).astype(dt)
     e = rng.uniform(-1, 1, (nc, nc)).astype(dt)
     mg = mgs[(name, 0)]
-    # bilinear weights are exact binary fractions: the only rounding is the sums
-    assert close(mg.interpolation2d(level, e), po.prolong(e), tol)
-    assert close(mg.interpolation_add(level, v, e), po.prolong_add(v, e), tol)
+    assert exact(mg.interpolation2d(level, e), po.prolong(e))
+    assert exact(mg.interpolation_add(level, v, e), po.prolong_add(v, e))
 
 
 def test_survey_pin_prolongation_of_ones_on_device(mgs):
@@ -118,7 +127,7 @@ def test_restriction_weight_modes(pkg, po):
     rng = np.random.default_rng(7)
     f = rng.uniform(-1, 1, (63, 63))
     with pkg.Multigrid(finest_level=6, coarsest_level=5, restrict_mode=pkg.RESTRICT_FW16) as mg:
-        assert close(mg.restriction2d(6, f), po.restrict(f, po.RESTRICT_FW16), 1e-13, scale=1.0)
+        assert exact(mg.restriction2d(6, f), po.restrict(f, po.RESTRICT_FW16))
 
 
 @pytest.mark.parametrize("level", [2, 5, 6, 7, 8])
@@ -143,13 +152,13 @@ def test_device_matches_committed_fixtures(mgs, level):
     for name, (dt, _, tol) in DT.items():
         v, f, e = g["v"].astype(dt), g["f"].astype(dt), g["e"].astype(dt)
         mj, mr = mgs[(name, 0)], mgs[(name, 1)]
-        assert close(mj.jacobirelaxation(level, v, f, 3), g[f"jacobi3_{name}"], 3 * tol)
-        assert close(mr.jacobirelaxation(level, v, f, 2), g[f"rbgs2_{name}"], 4 * tol)
-        assert close(mj.residual(level, v, f), g[f"residual_{name}"], 2 * tol, scale=8.0)
-        assert close(mj.restriction2d(level, f), g[f"restrict_{name}"], tol, scale=4.0)
-        assert close(mj.residual_restriction(level, v, f)[0], g[f"resrestrict_{name}"], 4 * tol, scale=32.0)
-        assert close(mj.interpolation2d(level, e), g[f"prolong_{name}"], tol)
-        assert close(mj.interpolation_add(level, v, e), g[f"prolong_add_{name}"], tol)
+        assert exact(mj.jacobirelaxation(level, v, f, 3), g[f"jacobi3_{name}"])
+        assert exact(mr.jacobirelaxation(level, v, f, 2), g[f"rbgs2_{name}"])
+        assert exact(mj.residual(level, v, f), g[f"residual_{name}"])
+        assert exact(mj.restriction2d(level, f), g[f"restrict_{name}"])
+        assert exact(mj.residual_restriction(level, v, f)[0], g[f"resrestrict_{name}"])
+        assert exact(mj.interpolation2d(level, e), g[f"prolong_{name}"])
+        assert exact(mj.interpolation_add(level, v, e), g[f"prolong_add_{name}"])
 
 
 def test_boundary_ring_and_padding_stay_zero(pkg):
