@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the 2-D Poisson multigrid hot path on MI355X.
+
+Metric (BASELINE.json): fine-grid stencil updates/sec (+ V-cycles to 1e-8
+residual) on the 8192^2 Poisson problem.
+
+A "step" is one V-cycle of the whole hierarchy over the resident problem
+(smoothing on every level, fused residual+restriction, prolongation+correction,
+exact bottom solve) followed by the residual-norm evaluation the solve loop
+makes after every cycle: mgx_solve(tol=0, max_cycles=K) runs exactly K of them.
+`value` = finest-level smoother point updates / wall time of those K steps,
+i.e. the coarse levels, the transfers, the bottom solve and the norm are all
+inside the time but only fine-grid updates are counted.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--level L] [--dtype f64|f32|mixed]
+                    [--smoother jacobi|rbgs] [--mu1 A --mu2 B] [--no-cpu-baseline]
+
+N = 1 : one process, libmgx (C-ABI) through ctypes, HIP events for the roofline.
+N > 1 : one process per GPU (torch.distributed over RCCL), the finest levels
+        slab-decomposed by rows with halo exchange between smoothing blocks
+        (multigrid_nikhil_c-_amd/dist.py); same problem at every N (strong scaling).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL / multi-process GPU work)
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Native libraries (RCCL prints a version banner) write to fd 1; the contract is
+# ONE JSON line on stdout, so everything else is routed to stderr and the result
+# line goes to the saved descriptor.
+_REAL_STDOUT = os.dup(1)
+os.dup2(2, 1)
+
+
+def emit(obj):
+    os.write(_REAL_STDOUT, (json.dumps(obj) + "\n").encode())
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md, chip table)
+HBM_COPY_CEILING_GBS = 6290.0  # measured float4-copy ceiling, same guide
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--level", type=int, default=13, help="finest level L: grid 2^L (8192^2 = BASELINE metric)")
+    p.add_argument("--coarsest", type=int, default=7, help="coarsest level (PS:18)")
+    p.add_argument("--mu1", type=int, default=10, help="pre-smoothing sweeps (PS:21)")
+    p.add_argument("--mu2", type=int, default=10, help="post-smoothing sweeps (PS:22)")
+    p.add_argument("--omega", type=float, default=2.0 / 3.0, help="Jacobi weight (PS:127)")
+    p.add_argument("--smoother", choices=["jacobi", "rbgs"], default="jacobi")
+    p.add_argument("--dtype", choices=["f64", "f32", "mixed"], default="f64")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-level", type=int, default=12, help="grid level of the bounded CPU-baseline sample")
+    return p.parse_args()
+
+
+DT = {"f32": 0, "f64": 1, "mixed": 2}
+BYTES = {"f32": 4, "f64": 8, "mixed": 4}
+
+
+def host_threads(omp_max):
+    """Threads this process may really use: CPU affinity and cgroup quota, not
+    the machine's core count (a 1-GPU box grants a 16-CPU share)."""
+    n = omp_max
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    env = os.environ.get("MGX_CPU_THREADS")
+    if env:
+        return max(1, int(env))
+    return max(1, min(n, 16 * max(1, int(os.environ.get("WORLD_SIZE", "1")))))
+
+
+def cpu_baseline(args):
+    """The oracle's Jacobi sweep timed on this box's host cores (bounded sample).
+    primary: matrix-free stencil, OpenMP over rows, all cores ('port');
+    extra  : reference-shaped CSR SpMV + scal/scal/add/add (PS:137-145), 1 thread."""
+    import numpy as np
+
+    from oracle import pyoracle as po
+
+    L = args.cpu_level
+    n = (1 << L) - 1
+    dt = np.float32 if args.dtype == "f32" else np.float64
+    b = po.rhs_sine(L).astype(dt)
+    u0 = po.fill_uniform((n, n), 12345).astype(dt)
+    threads = host_threads(po.lib().orc_max_threads())
+    # OpenMP flavour: warm once, then time
+    po.baseline_jacobi("omp", u0, b, 1, args.omega, threads)
+    sweeps = 20
+    t_omp, _ = po.baseline_jacobi("omp", u0, b, sweeps, args.omega, threads)
+    v_omp = n * n * sweeps / t_omp
+    sweeps_csr = 4
+    t_csr, _ = po.baseline_jacobi("csr", u0, b, sweeps_csr, args.omega)
+    v_csr = n * n * sweeps_csr / t_csr
+    main = {"value": v_omp, "unit": "updates/s", "cores": threads, "kind": "port",
+            "sample": f"{sweeps} weighted-Jacobi sweeps, {n}^2 {args.dtype if args.dtype != 'mixed' else 'f64'} grid, "
+                      f"matrix-free OpenMP oracle ({t_omp:.2f} s)"}
+    extra = {"value": v_csr, "unit": "updates/s", "cores": 1, "kind": "port",
+             "sample": f"{sweeps_csr} sweeps, {n}^2, reference-shaped CSR SpMV + scal/scal/add/add + copy as PS:137-145 ({t_csr:.2f} s)"}
+    return main, extra
+
+
+def pmc_traffic(workload_key):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3
+    PMC passes (profiles/*.json written by tools/pmc_summary.py); None if there
+    is no measurement for this exact workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh).get(workload_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def run_single(args):
+    import __graft_entry__ as ge
+
+    pkg = ge.load_package()
+    L = args.level
+    n = (1 << L) - 1
+    cfg = dict(finest_level=L, coarsest_level=min(args.coarsest, L), mu0=0, mu1=args.mu1, mu2=args.mu2,
+               omega=args.omega, smoother=1 if args.smoother == "rbgs" else 0, dtype=DT[args.dtype],
+               schedule=pkg.SCHEDULE_V, profile=1)
+    mg = pkg.Multigrid(**cfg)
+    # synthetic input, generated on the device: resident in HBM before any timing
+    mg.fill_rhs(1, 0.0)               # b = h^2 8 pi^2 sin(2 pi x) sin(2 pi y)
+    mg.fill_guess_random(12345)       # u0 ~ U(-1,1)
+    # ---- the "V-cycles to 1e-8" half of the metric (untimed here) ----
+    st0, hist0 = mg.solve(tol=1e-8, max_cycles=60)
+    cycles_to_tol = st0.cycles if st0.converged else None
+    solve_seconds = st0.seconds
+    # ---- warmup + timed steps on a fresh random guess ----
+    mg.fill_guess_random(12345)
+    if args.warmup > 0:
+        mg.solve(tol=0.0, max_cycles=args.warmup)
+    mg.profile_reset()
+    mg.synchronize()
+    t0 = time.perf_counter()
+    st, hist = mg.solve(tol=0.0, max_cycles=args.steps)
+    mg.synchronize()
+    t1 = time.perf_counter()
+    prof = mg.profile()
+    secs = t1 - t0
+    assert st.cycles == args.steps
+    updates = st.fine_updates
+    value = updates / secs
+    # ---- roofline of the dominant kernel: the finest-level smoother sweep ----
+    es = BYTES[args.dtype]
+    alg_bytes_per_launch = 3.0 * es * n * n          # read v + read b + write v' 
+    sm_ms = prof["ms"][0]               # MGX_PROF_SMOOTH_FINE
+    sm_launches = prof["launches"][0]
+    avg_ms = sm_ms / max(sm_launches, 1)
+    achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    kernel = ("k_rbgs" if args.smoother == "rbgs" else "k_jacobi_rows") + ("<double>" if es == 8 else "<float>")
+    wl_key = f"L{L}_{args.smoother}_{args.dtype}"
+    traffic = pmc_traffic(wl_key)
+    out = {
+        "metric": "fine_grid_stencil_updates_per_sec",
+        "value": value,
+        "unit": "updates/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": secs / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": f"2D Poisson {1 << L}^2 (n={n} interior), {L - cfg['coarsest_level'] + 1}-level V({args.mu1},{args.mu2}) cycle, "
+                        f"{'weighted Jacobi w=%.4f' % args.omega if args.smoother == 'jacobi' else 'red-black Gauss-Seidel'}, "
+                        f"{args.dtype}, exact bottom solve at {(1 << cfg['coarsest_level']) - 1}^2, "
+                        f"rhs h^2*8pi^2 sin(2pi x)sin(2pi y), u0~U(-1,1)",
+            "finest_level": L, "coarsest_level": cfg["coarsest_level"], "mu1": args.mu1, "mu2": args.mu2,
+            "smoother": args.smoother, "step": "one V-cycle + residual norm (mgx_solve loop body)",
+            "parallelism": "1 GPU",
+        },
+        "vcycles_to_1e-8": cycles_to_tol,
+        "seconds_to_1e-8": solve_seconds,
+        "residual_history_to_1e-8": [float(x) for x in hist0],
+        "roofline": {
+            "bound": "hbm",
+            "kernel": kernel,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+            "avg_launch_ms": avg_ms,
+            "launches_timed": sm_launches,
+            "smoother_updates_per_s": n * n / (avg_ms * 1e-3),
+            "how": "HIP events on the solver's stream around every finest-level smoothing block inside the timed steps",
+        },
+        "phase_ms_per_step": {
+            "smooth_fine": prof["ms"][0] / args.steps, "restrict_fine": prof["ms"][1] / args.steps,
+            "prolong_fine": prof["ms"][2] / args.steps, "norm_fine": prof["ms"][3] / args.steps,
+            "coarse_levels": prof["ms"][4] / args.steps,
+        },
+    }
+    mg.close()
+    if not args.no_cpu_baseline:
+        main, extra = cpu_baseline(args)
+        out["cpu_baseline"] = main
+        out["cpu_baseline_reference_shaped"] = extra
+    emit(out)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus <= 1 and world <= 1:
+        run_single(args)
+        return
+    from importlib import import_module
+
+    import __graft_entry__ as ge
+
+    ge.load_package()
+    dist_bench = import_module("multigrid_nikhil_c_amd.dist_bench")
+    dist_bench.run(args, emit)
+
+
+if __name__ == "__main__":
+    main()

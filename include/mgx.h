@@ -100,6 +100,14 @@ MGX_API int mgx_get_solution(mgx_handle h, void* u, size_t count);
  * double and everything else float). */
 MGX_API int mgx_set_level(mgx_handle h, int level, int which, const void* src, size_t count);
 MGX_API int mgx_get_level(mgx_handle h, int level, int which, void* dst, size_t count);
+/* Device-resident variants (inputs already in HBM): `grid` is a device pointer
+ * to a whole level in the library's own layout, rows 0..N times
+ * mgx_level_pitch(level, dtype) elements, Dirichlet ring and padding zero.
+ * Device-to-device copies on the handle's stream; block until done. */
+MGX_API int mgx_set_level_device(mgx_handle h, int level, int which, const void* grid);
+MGX_API int mgx_get_level_device(mgx_handle h, int level, int which, void* grid);
+/* zero a level vector (PS:613 / PS:630 initial guesses) */
+MGX_API int mgx_zero_level(mgx_handle h, int level, int which);
 /* Built-in right-hand sides, generated on the device:
  * kind 0: b = f h^2, the reference's load vector (PS:283-335, f = 4 at PS:123)
  * kind 1: b = h^2 8 pi^2 sin(2 pi x) sin(2 pi y)   (`f` ignored). */

@@ -31,7 +31,7 @@ PROF_SMOOTH_FINE, PROF_RESTRICT_FINE, PROF_PROLONG_FINE, PROF_NORM_FINE, PROF_CO
 EXPORTS = [
     "mgx_config_default", "mgx_create", "mgx_destroy", "mgx_last_error", "mgx_status_string",
     "mgx_level_n", "mgx_set_rhs", "mgx_set_guess", "mgx_get_solution", "mgx_set_level",
-    "mgx_get_level", "mgx_fill_rhs", "mgx_fill_guess_random", "mgx_smooth", "mgx_residual",
+    "mgx_get_level", "mgx_set_level_device", "mgx_get_level_device", "mgx_zero_level", "mgx_fill_rhs", "mgx_fill_guess_random", "mgx_smooth", "mgx_residual",
     "mgx_restrict", "mgx_restrict_rhs", "mgx_prolong_add", "mgx_prolong", "mgx_bottom_solve",
     "mgx_residual_norm", "mgx_vcycle", "mgx_fmg", "mgx_solve", "mgx_profile_reset",
     "mgx_profile_get", "mgx_time_smoother", "mgx_synchronize", "mgx_level_pitch",
@@ -99,6 +99,9 @@ def lib() -> C.CDLL:
         getattr(L, name).argtypes = [vp, vp, C.c_size_t]
     L.mgx_set_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
     L.mgx_get_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
+    L.mgx_set_level_device.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.mgx_get_level_device.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.mgx_zero_level.argtypes = [vp, C.c_int, C.c_int]
     L.mgx_fill_rhs.argtypes = [vp, C.c_int, C.c_double]
     L.mgx_fill_guess_random.argtypes = [vp, C.c_uint64]
     L.mgx_smooth.argtypes = [vp, C.c_int, C.c_int]
@@ -186,6 +189,16 @@ class Multigrid:
         a = np.empty((n, n), dtype=self.level_dtype(level, which))
         self._chk(lib().mgx_get_level(self._h, level, which, a.ctypes.data, a.size), "mgx_get_level")
         return a
+
+    def set_level_device(self, level, which, ptr):
+        """device-resident input: `ptr` addresses a whole level grid (rows 0..N x pitch)"""
+        self._chk(lib().mgx_set_level_device(self._h, level, which, ptr), "mgx_set_level_device")
+
+    def get_level_device(self, level, which, ptr):
+        self._chk(lib().mgx_get_level_device(self._h, level, which, ptr), "mgx_get_level_device")
+
+    def zero_level(self, level, which):
+        self._chk(lib().mgx_zero_level(self._h, level, which), "mgx_zero_level")
 
     def set_rhs(self, b):
         self.set_level(self.cfg.finest_level, VEC_B, b)

@@ -614,6 +614,47 @@ int mgx_get_level(mgx_handle s, int level, int which, void* dst, size_t count)
     return copy_out(s, *l, grid, dst, count);
 }
 
+int mgx_set_level_device(mgx_handle s, int level, int which, const void* grid)
+{
+    if (!s || !grid) return MGX_ERR_INVALID;
+    if (!level_ok(s, level)) return s->fail(MGX_ERR_INVALID, "level out of range");
+    void* dst = nullptr;
+    Level* l = pick(s, level, which, &dst);
+    if (which == MGX_VEC_R) {
+        int rc = ensure_r(s, *l);
+        if (rc) return rc;
+        dst = l->r;
+    }
+    if (!dst) return s->fail(MGX_ERR_INVALID, "unknown vector selector");
+    HIPCHK(s, hipMemcpyAsync(dst, grid, l->bytes, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    return MGX_OK;
+}
+
+int mgx_get_level_device(mgx_handle s, int level, int which, void* grid)
+{
+    if (!s || !grid) return MGX_ERR_INVALID;
+    if (!level_ok(s, level)) return s->fail(MGX_ERR_INVALID, "level out of range");
+    void* src = nullptr;
+    Level* l = pick(s, level, which, &src);
+    if (!src) return s->fail(MGX_ERR_STATE, "vector not available");
+    HIPCHK(s, hipMemcpyAsync(grid, src, l->bytes, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    return MGX_OK;
+}
+
+int mgx_zero_level(mgx_handle s, int level, int which)
+{
+    if (!s) return MGX_ERR_INVALID;
+    if (!level_ok(s, level)) return s->fail(MGX_ERR_INVALID, "level out of range");
+    void* dst = nullptr;
+    Level* l = pick(s, level, which, &dst);
+    if (!dst) return s->fail(MGX_ERR_STATE, "vector not available");
+    HIPCHK(s, hipMemsetAsync(dst, 0, l->bytes, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    return MGX_OK;
+}
+
 int mgx_set_rhs(mgx_handle s, const void* b, size_t count) { return s ? mgx_set_level(s, s->cfg.finest_level, MGX_VEC_B, b, count) : MGX_ERR_INVALID; }
 int mgx_set_guess(mgx_handle s, const void* u, size_t count) { return s ? mgx_set_level(s, s->cfg.finest_level, MGX_VEC_U, u, count) : MGX_ERR_INVALID; }
 int mgx_get_solution(mgx_handle s, void* u, size_t count) { return s ? mgx_get_level(s, s->cfg.finest_level, MGX_VEC_U, u, count) : MGX_ERR_INVALID; }
