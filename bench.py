@@ -60,7 +60,7 @@ def parse():
     p.add_argument("--smoother", choices=["jacobi", "rbgs"], default="jacobi")
     p.add_argument("--dtype", choices=["f64", "f32", "mixed"], default="f64")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-level", type=int, default=12, help="grid level of the bounded CPU-baseline sample")
+    p.add_argument("--cpu-level", type=int, default=13, help="grid level of the bounded CPU-baseline sample")
     return p.parse_args()
 
 
@@ -102,19 +102,25 @@ def cpu_baseline(args):
     b = po.rhs_sine(L).astype(dt)
     u0 = po.fill_uniform((n, n), 12345).astype(dt)
     threads = host_threads(po.lib().orc_max_threads())
-    # OpenMP flavour: warm once, then time
+    # OpenMP flavour on the full-size grid (three 0.5 GB arrays: beyond the L3):
+    # warm once, then ~10-30 core-seconds of sweeps
     po.baseline_jacobi("omp", u0, b, 1, args.omega, threads)
-    sweeps = 20
+    sweeps = 250
     t_omp, _ = po.baseline_jacobi("omp", u0, b, sweeps, args.omega, threads)
     v_omp = n * n * sweeps / t_omp
-    sweeps_csr = 4
-    t_csr, _ = po.baseline_jacobi("csr", u0, b, sweeps_csr, args.omega)
-    v_csr = n * n * sweeps_csr / t_csr
+    # reference-shaped flavour, one thread, on a quarter-size grid to stay bounded
+    Lc = max(L - 1, 6)
+    nc = (1 << Lc) - 1
+    bc = np.ascontiguousarray(b[:nc, :nc])
+    uc = np.ascontiguousarray(u0[:nc, :nc])
+    sweeps_csr = 100
+    t_csr, _ = po.baseline_jacobi("csr", uc, bc, sweeps_csr, args.omega)
+    v_csr = nc * nc * sweeps_csr / t_csr
     main = {"value": v_omp, "unit": "updates/s", "cores": threads, "kind": "port",
             "sample": f"{sweeps} weighted-Jacobi sweeps, {n}^2 {args.dtype if args.dtype != 'mixed' else 'f64'} grid, "
                       f"matrix-free OpenMP oracle ({t_omp:.2f} s)"}
     extra = {"value": v_csr, "unit": "updates/s", "cores": 1, "kind": "port",
-             "sample": f"{sweeps_csr} sweeps, {n}^2, reference-shaped CSR SpMV + scal/scal/add/add + copy as PS:137-145 ({t_csr:.2f} s)"}
+             "sample": f"{sweeps_csr} sweeps, {nc}^2, reference-shaped CSR SpMV + scal/scal/add/add + copy as PS:137-145 ({t_csr:.2f} s)"}
     return main, extra
 
 
@@ -162,15 +168,27 @@ def run_single(args):
     assert st.cycles == args.steps
     updates = st.fine_updates
     value = updates / secs
-    # ---- roofline of the dominant kernel: the finest-level smoother sweep ----
+    # ---- roofline of the dominant kernel: the finest-level smoother ----
+    # One launch of k_jacobi_fused<T,K> performs K sweeps in one pass over HBM, so
+    # the algorithmic bytes it is charged with are K * 3*sizeof(T) * n^2 (SURVEY
+    # §8d's per-update figure x the updates the launch performs) while its HBM
+    # traffic stays ~3*sizeof(T)*n^2: `frac` can exceed 1; `traffic` shows why.
     es = BYTES[args.dtype]
-    alg_bytes_per_launch = 3.0 * es * n * n          # read v + read b + write v' 
     sm_ms = prof["ms"][0]               # MGX_PROF_SMOOTH_FINE
-    sm_launches = prof["launches"][0]
-    avg_ms = sm_ms / max(sm_launches, 1)
+    sm_launches = max(prof["launches"][0], 1)
+    sm_sweeps = prof["sweeps"][0]
+    avg_ms = sm_ms / sm_launches
+    sweeps_per_launch = sm_sweeps / sm_launches
+    alg_bytes_per_launch = 3.0 * es * n * n * sweeps_per_launch
     achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    kernel = ("k_rbgs" if args.smoother == "rbgs" else "k_jacobi_rows") + ("<double>" if es == 8 else "<float>")
-    wl_key = f"L{L}_{args.smoother}_{args.dtype}"
+    tname = "double" if es == 8 else "float"
+    if args.smoother == "rbgs":
+        kernel = f"k_rbgs<{tname}>"
+    elif sweeps_per_launch > 1.0:
+        kernel = f"k_jacobi_fused<{tname},K> (K = {sweeps_per_launch:g} sweeps per launch on average)"
+    else:
+        kernel = f"k_jacobi_rows<{tname}>"
+    wl_key = f"L{L}_{args.smoother}_{args.dtype}_mu{args.mu1}"
     traffic = pmc_traffic(wl_key)
     out = {
         "metric": "fine_grid_stencil_updates_per_sec",
@@ -206,10 +224,12 @@ def run_single(args):
             "frac": achieved / HBM_PEAK_GBS,
             "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
             "traffic": traffic,
+            "hbm_physical_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
             "avg_launch_ms": avg_ms,
             "launches_timed": sm_launches,
-            "smoother_updates_per_s": n * n / (avg_ms * 1e-3),
+            "sweeps_timed": sm_sweeps,
+            "smoother_updates_per_s": n * n * sm_sweeps / (sm_ms * 1e-3),
             "how": "HIP events on the solver's stream around every finest-level smoothing block inside the timed steps",
         },
         "phase_ms_per_step": {

@@ -170,6 +170,8 @@ enum {
 typedef struct {
     double ms[MGX_PROF_COUNT];        /* accumulated HIP-event time */
     long long launches[MGX_PROF_COUNT]; /* kernel launches inside those intervals */
+    long long sweeps[MGX_PROF_COUNT];   /* smoother sweeps those launches performed (a fused
+                                           launch does several; 0 for non-smoother classes) */
 } mgx_profile;
 /* Valid when cfg.profile = 1; events are recorded on the handle's stream. */
 MGX_API int mgx_profile_reset(mgx_handle h);

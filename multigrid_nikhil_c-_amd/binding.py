@@ -60,7 +60,8 @@ class Stats(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("ms", C.c_double * PROF_COUNT), ("launches", C.c_longlong * PROF_COUNT)]
+    _fields_ = [("ms", C.c_double * PROF_COUNT), ("launches", C.c_longlong * PROF_COUNT),
+                ("sweeps", C.c_longlong * PROF_COUNT)]
 
 
 class Slab(C.Structure):
@@ -304,7 +305,7 @@ class Multigrid:
     def profile(self):
         p = Profile()
         self._chk(lib().mgx_profile_get(self._h, C.byref(p)), "mgx_profile_get")
-        return {"ms": list(p.ms), "launches": list(p.launches)}
+        return {"ms": list(p.ms), "launches": list(p.launches), "sweeps": list(p.sweeps)}
 
     def time_smoother(self, sweeps):
         ms = C.c_double()

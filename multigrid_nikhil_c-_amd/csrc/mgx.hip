@@ -49,7 +49,9 @@ struct Level {
     size_t esize() const { return f64 ? 8 : 4; }
 };
 
-struct EventPair { hipEvent_t a, b; int cls; long long launches; };
+struct EventPair { hipEvent_t a, b; int cls; long long launches; long long sweeps; };
+
+struct FuseCfg { int kmax; int rows; };   // temporal fusion of Jacobi sweeps (rows 0 = by grid size)
 
 } // namespace
 
@@ -67,10 +69,13 @@ struct mgx_solver {
     double* sum_host = nullptr;     // pinned
     std::string err;
     int rows_per_chunk = 0;         // 0 = auto (MGX_ROWS env overrides)
+    FuseCfg fuse{10, 0};            // temporal fusion of Jacobi sweeps (MGX_FUSE, MGX_FUSE_ROWS)
     // profiling
     std::vector<EventPair> ev_used, ev_free;
     double prof_ms[MGX_PROF_COUNT] = {0};
     long long prof_launches[MGX_PROF_COUNT] = {0};
+    long long prof_sweeps[MGX_PROF_COUNT] = {0};
+    int last_smooth_launches = 0;   // launches made by the most recent smoothing block
     double fine_updates = 0.0;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -94,10 +99,14 @@ struct Prof {
         EventPair p;
         if (!s->ev_free.empty()) { p = s->ev_free.back(); s->ev_free.pop_back(); }
         else { if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; }
-        p.cls = cls; p.launches = launches;
+        p.cls = cls; p.launches = launches; p.sweeps = 0;
         (void)hipEventRecord(p.a, s->stream);
         s->ev_used.push_back(p);
         idx = (int)s->ev_used.size() - 1;
+    }
+    void set(long long launches, long long sweeps)
+    {
+        if (idx >= 0) { s->ev_used[idx].launches = launches; s->ev_used[idx].sweeps = sweeps; }
     }
     ~Prof() { if (idx >= 0) (void)hipEventRecord(s->ev_used[idx].b, s->stream); }
 };
@@ -111,6 +120,7 @@ int prof_collect(mgx_solver* s)
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             s->prof_ms[p.cls] += ms;
             s->prof_launches[p.cls] += p.launches;
+            s->prof_sweeps[p.cls] += p.sweeps;
         }
         s->ev_free.push_back(p);
     }
@@ -141,6 +151,112 @@ void launch_jacobi(const T* vin, const T* b, T* vout, int N, long pitch, int row
     const Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, rpc);
     hipLaunchKernelGGL((k_jacobi<T>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
                        row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1);
+}
+
+// K sweeps in one pass (k_jacobi_fused); K in 2..5
+template <typename T, int K>
+void launch_jacobi_fused_k(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
+                           T c0, T c1, int bnd_lo, int bnd_hi, int R, hipStream_t st)
+{
+    constexpr int OUT = fused_out_lanes<K, VecOf<T>::W>();
+    Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, R);
+    g.strips = (N / VecOf<T>::W + OUT - 1) / OUT;
+    const long waves = (long)g.strips * g.chunks;
+    g.blocks = (int)(((waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
+    hipLaunchKernelGGL((k_jacobi_fused<T, K>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
+                       row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, bnd_lo, bnd_hi);
+}
+
+inline FuseCfg fuse_cfg()
+{
+    FuseCfg f;
+    f.kmax = env_int("MGX_FUSE", 10);          // 1 disables temporal fusion
+    if (f.kmax < 1) f.kmax = 1;
+    if (f.kmax > 10) f.kmax = 10;
+    f.rows = env_int("MGX_FUSE_ROWS", 0);      // 0: chosen from the grid size
+    if (f.rows < 0) f.rows = 0;
+    return f;
+}
+
+// Per-sweep throughput of k_jacobi_fused<T,K> relative to K = 1, measured on
+// MI355X at 8192^2 (tools/microbench, profiles/r01_fused_microbench.md).  0 = not
+// instantiated.  K = 5 is poor in float because it needs a second halo lane per
+// side for one extra column; K = 8 uses both lanes fully.
+constexpr double kFuseRate64[11] = {0, 1.00, 1.72, 2.52, 3.37, 4.11, 4.45, 0, 4.15, 0, 3.78};
+constexpr double kFuseRate32[11] = {0, 1.00, 1.65, 2.42, 3.13, 2.66, 3.60, 0, 3.89, 0, 3.24};
+
+// split mu sweeps into fused launches minimising the modelled time; parts[] gets
+// the K of each launch, returns their count
+inline int plan_fusion(int mu, int kmax, bool f64, int* parts)
+{
+    const double* rate = f64 ? kFuseRate64 : kFuseRate32;
+    std::vector<double> best(mu + 1, 1e300);
+    std::vector<int> pick(mu + 1, 1);
+    best[0] = 0.0;
+    for (int m = 1; m <= mu; ++m)
+        for (int k = 1; k <= std::min(m, std::min(kmax, 10)); ++k) {
+            if (rate[k] <= 0.0) continue;
+            // + a small per-launch cost so that equal-rate splits prefer fewer launches
+            const double c = best[m - k] + (double)k / rate[k] + 0.02;
+            if (c < best[m]) { best[m] = c; pick[m] = k; }
+        }
+    int n = 0;
+    for (int m = mu; m > 0; m -= pick[m]) parts[n++] = pick[m];
+    return n;
+}
+
+// mu Jacobi sweeps on rows [row_lo,row_hi) ping-ponging a <-> b2; returns the number
+// of launches' parity (1: result is in `b2`).  first/last: unknown rows are
+// (first-1, last) exclusive bounds, i.e. bnd_lo = first-1 and bnd_hi = last.
+// shrink: deep-halo mode, sweep k covers [row_lo-(mu-1-k), row_hi+(mu-1-k)) clipped.
+// rows_alloc: rows in the arrays (bounds are validated, never assumed).
+template <typename T>
+int jacobi_block(T* a, const T* rhs, T* b2, int N, long pitch, int rows_alloc, int row_lo, int row_hi, int mu,
+                 double omega, bool shrink, int first, int last, int rpc, const FuseCfg& fc, hipStream_t st, int* parity,
+                 int* launches = nullptr)
+{
+    const T om = (T)omega;
+    const T c0 = (T)(1.0 - (double)om);
+    const T c1 = (T)((double)om / 4.0);
+    T* src = a; T* dst = b2;
+    int flips = 0;
+    int done = 0;
+    // Fused launches pay (R + 2K)/R redundant rows and need enough chunks to fill
+    // the chip: measured worthwhile from 1024^2 up, with R growing with the grid.
+    const bool allow_fuse = fc.kmax > 1 && N >= 1024 && (row_hi - row_lo) >= 64;
+    int R = fc.rows;
+    if (R <= 0) { R = N / 128; if (R < 8) R = 8; if (R > 64) R = 64; }
+    std::vector<int> parts(mu > 0 ? mu : 1, 1);
+    const int nparts = allow_fuse ? plan_fusion(mu, fc.kmax, sizeof(T) == 8, parts.data()) : mu;
+    for (int p = 0; p < nparts; ++p) {
+        const int k = allow_fuse ? parts[p] : 1;
+        const int after = mu - (done + k);                       // sweeps still to come after this launch
+        const int ext = shrink ? after : 0;
+        const int lo = std::max(row_lo - ext, first), hi = std::min(row_hi + ext, last);
+        if (hi > lo) {
+            // rows read: [lo-k, hi+k) clipped to the global boundary rows
+            const int rd_lo = std::max(lo - k, first - 1), rd_hi = std::min(hi + k - 1, last);
+            if (rd_lo < 0 || rd_hi > rows_alloc - 1) return MGX_ERR_INVALID;
+            const int bl = first - 1, bh = last;
+            switch (k) {
+                case 1: launch_jacobi<T>(src, rhs, dst, N, pitch, lo, hi, omega, rpc, st); break;
+                case 2: launch_jacobi_fused_k<T, 2>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
+                case 3: launch_jacobi_fused_k<T, 3>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
+                case 4: launch_jacobi_fused_k<T, 4>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
+                case 5: launch_jacobi_fused_k<T, 5>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
+                case 6: launch_jacobi_fused_k<T, 6>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
+                case 8: launch_jacobi_fused_k<T, 8>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
+                case 10: launch_jacobi_fused_k<T, 10>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
+                default: return MGX_ERR_INVALID;
+            }
+        }
+        std::swap(src, dst);
+        ++flips;
+        done += k;
+    }
+    *parity = flips & 1;
+    if (launches) *launches = flips;
+    return MGX_OK;
 }
 
 template <typename T>
@@ -310,13 +426,19 @@ template <typename T>
 void smooth_t(mgx_solver* s, Level& l, int mu)
 {
     const int rpc = s->rows_per_chunk;
-    for (int k = 0; k < mu; ++k) {
-        if (s->cfg.smoother == MGX_SMOOTHER_RBGS)
+    if (s->cfg.smoother == MGX_SMOOTHER_RBGS) {
+        for (int k = 0; k < mu; ++k) {
             launch_rbgs<T>((const T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, 1, l.N, 0, 0, l.N, rpc, s->stream);
-        else
-            launch_jacobi<T>((const T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, 1, l.N, s->cfg.omega, rpc, s->stream);
-        std::swap(l.u, l.tmp);
+            std::swap(l.u, l.tmp);
+        }
+        s->last_smooth_launches = mu;
+        return;
     }
+    int parity = 0, launches = 0;
+    (void)jacobi_block<T>((T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, l.rows, 1, l.N, mu, s->cfg.omega, false,
+                          1, l.N, rpc, s->fuse, s->stream, &parity, &launches);
+    s->last_smooth_launches = launches;
+    if (parity) std::swap(l.u, l.tmp);
 }
 
 void smooth(mgx_solver* s, int level, int mu)
@@ -326,6 +448,7 @@ void smooth(mgx_solver* s, int level, int mu)
     const bool fine = (level == s->cfg.finest_level);
     Prof p(s, fine ? MGX_PROF_SMOOTH_FINE : MGX_PROF_COARSE, mu);
     if (l.f64) smooth_t<double>(s, l, mu); else smooth_t<float>(s, l, mu);
+    p.set(s->last_smooth_launches, mu);
     if (fine) s->fine_updates += (double)mu * (double)(l.N - 1) * (double)(l.N - 1);
 }
 
@@ -529,6 +652,7 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
     s->mixed = (cfg->dtype == MGX_DTYPE_MIXED);
     s->work_f64 = (cfg->dtype == MGX_DTYPE_F64);
     s->rows_per_chunk = env_int("MGX_ROWS", 0);
+    s->fuse = fuse_cfg();
     int rc = MGX_OK;
     auto bail = [&](int code) { g_create_error = s->err; mgx_destroy(s); return code; };
     if (hipStreamCreate(&s->stream) != hipSuccess) { s->err = "hipStreamCreate failed"; return bail(MGX_ERR_HIP); }
@@ -878,7 +1002,7 @@ int mgx_profile_reset(mgx_handle s)
     if (!s) return MGX_ERR_INVALID;
     int rc = prof_collect(s);
     if (rc) return rc;
-    for (int i = 0; i < MGX_PROF_COUNT; ++i) { s->prof_ms[i] = 0.0; s->prof_launches[i] = 0; }
+    for (int i = 0; i < MGX_PROF_COUNT; ++i) { s->prof_ms[i] = 0.0; s->prof_launches[i] = 0; s->prof_sweeps[i] = 0; }
     return MGX_OK;
 }
 
@@ -887,7 +1011,11 @@ int mgx_profile_get(mgx_handle s, mgx_profile* out)
     if (!s || !out) return MGX_ERR_INVALID;
     int rc = prof_collect(s);
     if (rc) return rc;
-    for (int i = 0; i < MGX_PROF_COUNT; ++i) { out->ms[i] = s->prof_ms[i]; out->launches[i] = s->prof_launches[i]; }
+    for (int i = 0; i < MGX_PROF_COUNT; ++i) {
+        out->ms[i] = s->prof_ms[i];
+        out->launches[i] = s->prof_launches[i];
+        out->sweeps[i] = s->prof_sweeps[i];
+    }
     return MGX_OK;
 }
 
@@ -941,18 +1069,16 @@ int mgx_slab_jacobi(const mgx_slab* s, void* u, const void* b, void* tmp, int ro
     const long pitch = level_pitch(s->level, s->dtype);
     const int first = 1 - s->row0, last = N - s->row0;      // unknown rows are [first, last)
     const int rpc = env_int("MGX_ROWS", 0);
-    void* src = u; void* dst = tmp;
-    for (int k = 0; k < mu; ++k) {
-        const int ext = shrink ? (mu - 1 - k) : 0;
-        const int lo = std::max(row_lo - ext, first), hi = std::min(row_hi + ext, last);
-        if (lo < 1 || hi > s->rows - 1) return MGX_ERR_INVALID;       // rows lo-1 and hi are read
-        if (s->dtype == MGX_DTYPE_F64)
-            launch_jacobi<double>((const double*)src, (const double*)b, (double*)dst, N, pitch, lo, hi, omega, rpc, (hipStream_t)stream);
-        else
-            launch_jacobi<float>((const float*)src, (const float*)b, (float*)dst, N, pitch, lo, hi, omega, rpc, (hipStream_t)stream);
-        std::swap(src, dst);
-    }
-    if (result_in_tmp) *result_in_tmp = (mu & 1);
+    const FuseCfg fc = fuse_cfg();
+    int parity = 0, rc;
+    if (s->dtype == MGX_DTYPE_F64)
+        rc = jacobi_block<double>((double*)u, (const double*)b, (double*)tmp, N, pitch, s->rows, row_lo, row_hi, mu,
+                                  omega, shrink != 0, first, last, rpc, fc, (hipStream_t)stream, &parity);
+    else
+        rc = jacobi_block<float>((float*)u, (const float*)b, (float*)tmp, N, pitch, s->rows, row_lo, row_hi, mu,
+                                 omega, shrink != 0, first, last, rpc, fc, (hipStream_t)stream, &parity);
+    if (rc) return rc;
+    if (result_in_tmp) *result_in_tmp = parity;
     return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_HIP;
 }
 

@@ -310,6 +310,79 @@ k_rbgs(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vou
 }
 
 // =============================================================================
+// K weighted-Jacobi sweeps in ONE pass over the data (temporal blocking):
+//   vout = J^K(vin),  HBM traffic 3 sizeof(T) per point per K sweeps.
+// The single-sweep kernel already moves its algorithmic bytes at ~71 % of the
+// HBM peak; the only way past that is fewer bytes per update.  A wave marches
+// down its chunk keeping, for every sweep level j < K, a 3-row window of level-j
+// values in registers: loading input row y makes level-1 row y-1 computable,
+// which makes level-2 row y-2 computable, ... and level-K row y-K is stored.
+// Chunk edges recompute K halo rows per level (L2-served), strip edges use
+// HL = ceil(K / W) halo lanes per side, so no wave depends on another wave.
+// Each level performs exactly the arithmetic of one k_jacobi sweep, Dirichlet
+// rows/columns are re-zeroed at every level: the result is bit-identical to K
+// single sweeps.
+// bnd_lo / bnd_hi: local indices of the global boundary rows (slabs); rows
+// [max(row_lo-K, bnd_lo), min(row_hi+K-1, bnd_hi)] must exist.
+// =============================================================================
+template <typename T, int K>
+__global__ void __launch_bounds__(kBlock)
+k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
+               int N, long pitch, int row_lo, int row_hi, int R, int strips, int chunks,
+               T c0, T c1, int bnd_lo, int bnd_hi)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int W = VecOf<T>::W;
+    constexpr int HL = (K + W - 1) / W;           // halo lanes per side
+    constexpr int OUT = kWave - 2 * HL;           // storing lanes per wave
+    const Tile t = wave_tile(strips, chunks);
+    if (!t.active) return;
+    const int lane = threadIdx.x & 63;
+    const int vx = t.strip * OUT - HL + lane;
+    const long col = (long)vx * W;
+    const bool ld = (vx >= 0) && (col + W <= pitch);
+    const bool st = (lane >= HL) && (lane < kWave - HL) && (vx < N / W);
+    const int r0 = row_lo + t.chunk * R;
+    const int r1 = min(r0 + R, row_hi);
+    const T* pv = vin + col;
+    const T* pb = rhs + col;
+    T* po = vout + col;
+    const V Z = vzero((V*)nullptr);
+
+    V lev[K][3];          // lev[j] = level-j rows (y-j-2, y-j-1, y-j)
+    V bw[K];              // bw[j]  = rhs row y-1-j
+#pragma unroll
+    for (int j = 0; j < K; ++j) { lev[j][0] = Z; lev[j][1] = Z; lev[j][2] = Z; bw[j] = Z; }
+
+    for (int y = r0 - K; y < r1 + K; ++y) {
+        // level 0: input row y; rhs row y-1 (consumed by the level-1 update of row y-1)
+        const V in = vload<V>(pv + (long)y * pitch, ld && y >= bnd_lo && y <= bnd_hi);
+        // rhs rows are needed only where some level is: [r0-K+1, r1+K-1)
+        const V bn = vload<V>(pb + (long)(y - 1) * pitch,
+                              ld && (y - 1) > bnd_lo && (y - 1) < bnd_hi && y >= r0 - K + 2 && y < r1 + K);
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) bw[j] = bw[j - 1];
+        bw[0] = bn;
+        lev[0][0] = lev[0][1]; lev[0][1] = lev[0][2]; lev[0][2] = in;
+#pragma unroll
+        for (int j = 1; j <= K; ++j) {
+            // level-j row (y - j) from level-(j-1) rows (y-j-1, y-j, y-j+1) and rhs row y-j
+            const int row = y - j;
+            V o = jacobi_vec<T>(lev[j - 1][0], lev[j - 1][1], lev[j - 1][2], bw[j - 1], c0, c1);
+            mask_cols(o, col, N);
+            if (!(row > bnd_lo && row < bnd_hi)) o = Z;          // Dirichlet rows stay zero
+            if (j < K) {
+                lev[j][0] = lev[j][1]; lev[j][1] = lev[j][2]; lev[j][2] = o;
+            } else {
+                vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);
+            }
+        }
+    }
+}
+
+template <int K, int W> constexpr int fused_out_lanes() { return kWave - 2 * ((K + W - 1) / W); }
+
+// =============================================================================
 // residual r = b - A v   (PS:604-607: Av = LU v + D v = -(N+W+E+S) + 4 v)
 // =============================================================================
 __device__ __forceinline__ double2 residual_vec(const double2& up, const double2& cur, const double2& dn, const double2& bb)

@@ -186,3 +186,28 @@ def test_smoother_is_linear_and_zero_preserving(mgs):
     b = mg.jacobirelaxation(8, 2 * v, 2 * f, 2)
     assert np.array_equal(b, 2 * a)           # scaling by 2 is exact in binary
     assert np.all(mg.jacobirelaxation(8, 0 * v, 0 * f, 3) == 0)
+
+
+@pytest.mark.parametrize("name", ["f64", "f32"])
+@pytest.mark.parametrize("kmax", [2, 3, 4, 5, 10])
+def test_fused_sweeps_are_bit_identical_to_single_sweeps(pkg, po, name, kmax, monkeypatch):
+    """temporal fusion (k_jacobi_fused: K sweeps per pass) must not change a bit"""
+    dt, code, _ = DT[name]
+    monkeypatch.setenv("MGX_FUSE", str(kmax))
+    monkeypatch.setenv("MGX_FUSE_ROWS", "16")
+    rng = np.random.default_rng(700 + kmax)
+    with pkg.Multigrid(finest_level=11, coarsest_level=8, dtype=code, bottom=pkg.BOTTOM_SMOOTH) as mg:
+        for level in (8, 10, 11):
+            n = (1 << level) - 1
+            v = rng.uniform(-1, 1, (n, n)).astype(dt)
+            f = rng.uniform(-1, 1, (n, n)).astype(dt)
+            # with kmax = 10 the planner uses K = 6, 8, 10 and mixed splits as well
+            for mu in sorted({kmax, kmax + 1, 6, 8, 10, 14} if kmax == 10 else {kmax, kmax + 1, 10}):
+                assert exact(mg.jacobirelaxation(level, v, f, mu), po.jacobi(v, f, mu)), (name, kmax, level, mu)
+    # data largest next to the Dirichlet ring: every level of the fusion must re-zero the ring
+    with pkg.Multigrid(finest_level=10, coarsest_level=7, dtype=code, bottom=pkg.BOTTOM_SMOOTH) as mg:
+        n = 1023
+        v = np.zeros((n, n), dtype=dt); f = np.zeros((n, n), dtype=dt)
+        v[0, :] = v[-1, :] = v[:, 0] = v[:, -1] = 1
+        f[0, 0] = f[-1, -1] = 3
+        assert exact(mg.jacobirelaxation(10, v, f, kmax), po.jacobi(v, f, kmax))

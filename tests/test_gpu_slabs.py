@@ -31,11 +31,13 @@ def interior(t, level):
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
-@pytest.mark.parametrize("smoother", ["jacobi", "rbgs"])
-def test_two_slabs_with_deep_halo_equal_whole_grid(pkg, po, dt, smoother):
+@pytest.mark.parametrize("smoother,level,mu,fuse", [("jacobi", 7, 3, 1), ("rbgs", 7, 3, 1), ("jacobi", 10, 5, 2),
+                                                    ("jacobi", 10, 10, 4), ("jacobi", 10, 7, 5), ("jacobi", 10, 10, 10)])
+def test_two_slabs_with_deep_halo_equal_whole_grid(pkg, po, dt, smoother, level, mu, fuse, monkeypatch):
     torch = _torch()
     L = pkg.lib()
-    level, mu = 7, 3
+    monkeypatch.setenv("MGX_FUSE", str(fuse))
+    monkeypatch.setenv("MGX_FUSE_ROWS", "16")
     N = 1 << level
     code = pkg.DTYPE_F64 if dt == np.float64 else pkg.DTYPE_F32
     rng = np.random.default_rng(11)

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <type_traits>
 #include <vector>
 
 using namespace mgx;
@@ -107,6 +108,8 @@ k_jacobi_b(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__
     }
 }
 
+static bool g_fused_only = false;
+
 struct Timer {
     hipEvent_t a, b;
     Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
@@ -178,6 +181,7 @@ void run_level(int level, int iters)
                pts * bytes_per_pt / (ms * 1e-3) / 1e9, pts / (ms * 1e-3) / 1e9);
         fflush(stdout);
     };
+    if (!g_fused_only)
     {   // ceiling: same arrays, 2 reads + 1 write, grid-stride
         for (int blocks : {2048, 4096, 16384}) {
             float ms = tm.run([&] { hipLaunchKernelGGL(k_stream3<T>, dim3(blocks), dim3(256), 0, 0, u, b, tmp, elems / W); }, 3, iters);
@@ -186,6 +190,7 @@ void run_level(int level, int iters)
         }
     }
     for (int R : {4, 8, 16, 32, 64, 128}) {
+        if (g_fused_only) break;
         const Launch g = make_launch(N, W, N - 1, R);
         T* src = u; T* dst = tmp;
         float ms = tm.run([&] {
@@ -196,6 +201,7 @@ void run_level(int level, int iters)
         report(nm, ms, 3.0 * sizeof(T));
     }
     for (int R : {8, 16, 32, 64}) {
+        if (g_fused_only) break;
         Launch g = make_launch(N, W, N - 1, R);
         g.strips = (N / W + 63) / 64;
         long waves = (long)g.strips * g.chunks;
@@ -218,6 +224,35 @@ void run_level(int level, int iters)
             std::swap(src, dst);
         }, 3, iters);
         report("jacobi naive (row per wave)", ms, 3.0 * sizeof(T));
+    }
+    auto fused = [&](auto kc, int R) {
+        constexpr int K = decltype(kc)::value;
+        constexpr int OUT = fused_out_lanes<K, W>();
+        Launch g = make_launch(N, W, N - 1, R);
+        g.strips = (N / W + OUT - 1) / OUT;
+        const long waves = (long)g.strips * g.chunks;
+        g.blocks = (int)(((waves + 3) / 4 + 7) / 8 * 8);
+        T* src = u; T* dst = tmp;
+        float ms = tm.run([&] {
+            hipLaunchKernelGGL((k_jacobi_fused<T, K>), dim3(g.blocks), dim3(kBlock), 0, 0, src, b, dst, N, pitch, 1, N, g.R, g.strips, g.chunks, c0, c1, 0, N);
+            std::swap(src, dst);
+        }, 3, iters);
+        char nm[64]; snprintf(nm, sizeof nm, "jacobi fused K=%d R=%d (per sweep)", K, R);
+        report(nm, ms / K, 3.0 * sizeof(T));
+    };
+    for (int R : {8, 16, 32, 64, 128}) {
+        if (R * 4 > N) continue;
+        fused(std::integral_constant<int, 2>{}, R);
+        fused(std::integral_constant<int, 3>{}, R);
+        fused(std::integral_constant<int, 4>{}, R);
+        fused(std::integral_constant<int, 5>{}, R);
+        fused(std::integral_constant<int, 6>{}, R);
+        fused(std::integral_constant<int, 8>{}, R);
+        fused(std::integral_constant<int, 10>{}, R);
+    }
+    if (g_fused_only) {
+        CK(hipFree(u)); CK(hipFree(b)); CK(hipFree(tmp)); CK(hipFree(cb)); CK(hipFree(cu));
+        return;
     }
     for (int R : {8, 16, 32, 64}) {
         const Launch g = make_launch(N, W, N - 1, R);
@@ -265,6 +300,7 @@ int main(int argc, char** argv)
     const int level = argc > 1 ? atoi(argv[1]) : 13;
     const int iters = argc > 2 ? atoi(argv[2]) : 20;
     const char* which = argc > 3 ? argv[3] : "both";
+    g_fused_only = argc > 4 && argv[4][0] == 'f';
     if (level < 6 || level > 14) { printf("level must be 6..14\n"); return 1; }
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
