@@ -185,7 +185,9 @@ def run_single(args):
     if args.smoother == "rbgs":
         kernel = f"k_rbgs<{tname}>"
     elif sweeps_per_launch > 1.0:
-        kernel = f"k_jacobi_fused<{tname},K> (K = {sweeps_per_launch:g} sweeps per launch on average)"
+        kernel = (f"k_jacobi_fused<{tname},K> / k_jacobi_cycle<{tname},K,PRE,POST> "
+                  f"(finest-level smoother passes, K = {sweeps_per_launch:g} sweeps per launch on average; "
+                  f"the cycle's correction, residual+restriction and norm ride in the same passes)")
     else:
         kernel = f"k_jacobi_rows<{tname}>"
     wl_key = f"L{L}_{args.smoother}_{args.dtype}_mu{args.mu1}"

@@ -76,6 +76,9 @@ struct mgx_solver {
     long long prof_launches[MGX_PROF_COUNT] = {0};
     long long prof_sweeps[MGX_PROF_COUNT] = {0};
     int last_smooth_launches = 0;   // launches made by the most recent smoothing block
+    int fold = 1;                   // fold transfers / norm into smoother passes (MGX_FOLD)
+    bool want_norm = false;         // the top-level post-smoothing should also produce ||r||^2 partials
+    int norm_blocks_ready = 0;      // > 0: partial[] holds that many sums of r^2 for the current U
     double fine_updates = 0.0;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -259,6 +262,51 @@ int jacobi_block(T* a, const T* rhs, T* b2, int N, long pitch, int rows_alloc, i
     return MGX_OK;
 }
 
+// ---- smoother passes with the cycle's transfers folded in (k_jacobi_cycle) ----------
+struct FoldArgs {
+    const void* coarse_e = nullptr;   // PRE: correction to add while loading
+    void* coarse_b = nullptr;         // POST 1: restricted residual
+    void* coarse_zero = nullptr;      // POST 1: coarse guess to zero
+    int restrict_mode = 0;
+    double* partial = nullptr;        // POST 2: per-block sums of r^2
+    long cpitch = 0;
+};
+
+template <typename T, int K, int PRE, int POST>
+int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N, long pitch, T c0, T c1, int R,
+                   hipStream_t st)
+{
+    constexpr int OUT = cycle_out_lanes<K, POST, VecOf<T>::W>();
+    if (R & 1) ++R;                                    // chunks must start on odd rows (POST = 1)
+    Launch g = make_launch(N, VecOf<T>::W, N - 1, R);
+    g.strips = (N / VecOf<T>::W + OUT - 1) / OUT;
+    const long waves = (long)g.strips * g.chunks;
+    g.blocks = (int)(((waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
+    const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
+    hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout,
+                       (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
+                       1, N, g.R, g.strips, g.chunks, c0, c1);
+    return g.blocks;
+}
+
+template <typename T, int PRE, int POST>
+int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, int N, long pitch, T c0, T c1, int R,
+                 hipStream_t st)
+{
+    switch (K) {
+        case 1: return launch_cycle_k<T, 1, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        case 2: return launch_cycle_k<T, 2, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        case 3: return launch_cycle_k<T, 3, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        case 4: return launch_cycle_k<T, 4, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        case 5: return launch_cycle_k<T, 5, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        case 6: return launch_cycle_k<T, 6, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        case 8: return launch_cycle_k<T, 8, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        default: return -1;
+    }
+}
+
+inline bool cycle_k_supported(int K) { return K >= 1 && K <= 8 && K != 7; }
+
 template <typename T>
 void launch_rbgs(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
                  int row_parity, int bnd_lo, int bnd_hi, int rpc, hipStream_t st)
@@ -441,6 +489,100 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
     if (parity) std::swap(l.u, l.tmp);
 }
 
+// mu Jacobi sweeps on a whole level with the prolongation+correction applied while
+// loading (pre_e: coarse correction, may be null) and/or the residual restriction
+// (post = 1) or the residual norm (post = 2) produced by the last pass.
+// Returns false when this level / configuration is not eligible (caller then
+// uses the stand-alone kernels); on success *norm_blocks = partial sums written.
+template <typename T>
+bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool pre, int post, int* launches,
+                     int* norm_blocks)
+{
+    if (!s->fold || s->cfg.smoother != MGX_SMOOTHER_JACOBI || mu < 1 || l.N < 1024 || s->fuse.kmax < 1) return false;
+    int parts[64];
+    if (mu > 64) return false;
+    const int kmax = std::min(s->fuse.kmax, 8);
+    const int np = plan_fusion(mu, kmax, sizeof(T) == 8, parts);
+    for (int p = 0; p < np; ++p)
+        if (!cycle_k_supported(parts[p])) return false;
+    const T om = (T)s->cfg.omega;
+    const T c0 = (T)(1.0 - (double)om);
+    const T c1 = (T)((double)om / 4.0);
+    int R = s->fuse.rows;
+    if (R <= 0) { R = l.N / 128; if (R < 8) R = 8; if (R > 64) R = 64; }
+    FoldArgs fa;
+    fa.restrict_mode = s->cfg.restrict_mode;
+    fa.partial = s->partial;
+    if (coarse) { fa.cpitch = coarse->pitch; fa.coarse_e = coarse->u; fa.coarse_b = coarse->b; fa.coarse_zero = coarse->u; }
+    T* src = (T*)l.u; T* dst = (T*)l.tmp;
+    const T* b = (const T*)l.b;
+    for (int p = 0; p < np; ++p) {
+        const bool first = (p == 0), last = (p == np - 1);
+        const bool P = pre && first;
+        const int Q = last ? post : 0;
+        int blocks = 0;
+        if (P && Q == 2) blocks = launch_cycle<T, 1, 2>(parts[p], src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
+        else if (P && Q == 1) return false;   // never requested
+        else if (P) blocks = launch_cycle<T, 1, 0>(parts[p], src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
+        else if (Q == 1) blocks = launch_cycle<T, 0, 1>(parts[p], src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
+        else if (Q == 2) blocks = launch_cycle<T, 0, 2>(parts[p], src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
+        else {
+            const int k = parts[p];
+            if (k == 1) launch_jacobi<T>(src, b, dst, l.N, l.pitch, 1, l.N, s->cfg.omega, s->rows_per_chunk, s->stream);
+            else {
+                int par = 0;
+                FuseCfg one = s->fuse; one.kmax = k;
+                // a single plain fused launch of exactly k sweeps
+                switch (k) {
+                    case 2: launch_jacobi_fused_k<T, 2>(src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, R, s->stream); break;
+                    case 3: launch_jacobi_fused_k<T, 3>(src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, R, s->stream); break;
+                    case 4: launch_jacobi_fused_k<T, 4>(src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, R, s->stream); break;
+                    case 5: launch_jacobi_fused_k<T, 5>(src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, R, s->stream); break;
+                    case 6: launch_jacobi_fused_k<T, 6>(src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, R, s->stream); break;
+                    default: launch_jacobi_fused_k<T, 8>(src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, R, s->stream); break;
+                }
+                (void)par; (void)one;
+            }
+        }
+        if (Q == 2) {
+            if (blocks < 0 || blocks > s->partial_cap) return false;   // cannot happen: checked below before launch
+            *norm_blocks = blocks;
+        }
+        std::swap(src, dst);
+    }
+    if (np & 1) std::swap(l.u, l.tmp);
+    *launches = np;
+    return true;
+}
+
+// pre-check used before any launch is made (so a `false` never leaves a half-done block)
+bool fold_eligible(const mgx_solver* s, const Level& l, int mu)
+{
+    if (!s->fold || s->cfg.smoother != MGX_SMOOTHER_JACOBI || mu < 1 || mu > 64 || l.N < 1024) return false;
+    int parts[64];
+    const int np = plan_fusion(mu, std::min(s->fuse.kmax, 8), l.f64, parts);
+    for (int p = 0; p < np; ++p)
+        if (!cycle_k_supported(parts[p])) return false;
+    return true;
+}
+
+bool smooth_folded(mgx_solver* s, int level, int mu, bool pre, int post)
+{
+    Level& l = s->lv[level];
+    if (!fold_eligible(s, l, mu)) return false;
+    const Level* coarse = (pre || post == 1) ? &s->lv[level - 1] : nullptr;
+    const bool fine = (level == s->cfg.finest_level);
+    Prof p(s, fine ? MGX_PROF_SMOOTH_FINE : MGX_PROF_COARSE, mu);
+    int launches = 0, nb = 0;
+    const bool ok = l.f64 ? smooth_folded_t<double>(s, l, mu, coarse, pre, post, &launches, &nb)
+                          : smooth_folded_t<float>(s, l, mu, coarse, pre, post, &launches, &nb);
+    if (!ok) return false;
+    p.set(launches, mu);
+    if (post == 2) s->norm_blocks_ready = nb;
+    if (fine) s->fine_updates += (double)mu * (double)(l.N - 1) * (double)(l.N - 1);
+    return true;
+}
+
 void smooth(mgx_solver* s, int level, int mu)
 {
     if (mu <= 0) return;
@@ -501,11 +643,20 @@ void vcycle(mgx_solver* s, int level)
         }
         return;
     }
-    smooth(s, level, s->cfg.mu1);                             // PS:581
-    restrict_level(s, level, true, true);                     // PS:604-613
+    // PS:581 pre-smoothing + PS:604-613 residual, restriction, zero coarse guess:
+    // one set of passes when the level is eligible for folding
+    if (!smooth_folded(s, level, s->cfg.mu1, false, 1)) {
+        smooth(s, level, s->cfg.mu1);                         // PS:581
+        restrict_level(s, level, true, true);                 // PS:604-613
+    }
+    const bool top_norm = s->want_norm && level == s->cfg.finest_level;
+    s->want_norm = false;                                     // only the outermost level reports the norm
     vcycle(s, level - 1);                                     // PS:617
-    prolong_level(s, level, true);                            // PS:620-624
-    smooth(s, level, s->cfg.mu2);                             // PS:625
+    // PS:620-624 correction + PS:625 post-smoothing (+ the cycle's residual norm)
+    if (!smooth_folded(s, level, s->cfg.mu2, true, top_norm ? 2 : 0)) {
+        prolong_level(s, level, true);                        // PS:620-624
+        smooth(s, level, s->cfg.mu2);                         // PS:625
+    }
 }
 
 int zero_u(mgx_solver* s, int level)
@@ -537,7 +688,12 @@ int fmg(mgx_solver* s)
 // ||B - A U|| of an arbitrary grid pair (double or float)
 int residual_norm_grid(mgx_solver* s, const Level& l, const void* u, const void* b, double* out, int cls)
 {
-    {
+    if (s->norm_blocks_ready > 0 && u == s->lv[s->cfg.finest_level].u && !s->mixed) {
+        // the last post-smoothing pass already summed (b - A u)^2 per block
+        Prof p(s, cls, 1);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, s->stream, s->partial, s->norm_blocks_ready,
+                           s->sum_dev);
+    } else {
         Prof p(s, cls, 2);
         if (l.f64)
             launch_residual<double, 1>((const double*)u, (const double*)b, nullptr, 0, s->partial, s->sum_dev, 1.0,
@@ -546,6 +702,7 @@ int residual_norm_grid(mgx_solver* s, const Level& l, const void* u, const void*
             launch_residual<float, 1>((const float*)u, (const float*)b, nullptr, 0, s->partial, s->sum_dev, 1.0,
                                       l.N, l.pitch, 1, l.N, s->rows_per_chunk, s->stream, s->partial_cap);
     }
+    s->norm_blocks_ready = 0;
     HIPCHK(s, hipMemcpyAsync(s->sum_host, s->sum_dev, sizeof(double), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(s, hipStreamSynchronize(s->stream));
     *out = std::sqrt(*s->sum_host);
@@ -653,6 +810,7 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
     s->work_f64 = (cfg->dtype == MGX_DTYPE_F64);
     s->rows_per_chunk = env_int("MGX_ROWS", 0);
     s->fuse = fuse_cfg();
+    s->fold = env_int("MGX_FOLD", 1);
     int rc = MGX_OK;
     auto bail = [&](int code) { g_create_error = s->err; mgx_destroy(s); return code; };
     if (hipStreamCreate(&s->stream) != hipSuccess) { s->err = "hipStreamCreate failed"; return bail(MGX_ERR_HIP); }
@@ -924,8 +1082,9 @@ int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double
         hist.push_back(r);
         for (k = 0; k < max_cycles; ++k) {
             if (hist[k] <= tol * hist[0]) break;
+            s->norm_blocks_ready = 0;
             if (k == 0 && do_fmg) { if ((rc = fmg(s))) return rc; }
-            else vcycle(s, L);
+            else { s->want_norm = true; vcycle(s, L); s->want_norm = false; }
             if ((rc = residual_norm_grid(s, l, l.u, l.b, &r, MGX_PROF_NORM_FINE))) return rc;
             hist.push_back(r);
         }

@@ -32,13 +32,32 @@ k_dst_gemm(const double* __restrict__ A, const void* __restrict__ Bv, void* __re
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i >= n || j >= n) return;
+    // The sum runs in k order with one accumulator (deterministic); the loads are
+    // independent of it, so they are issued 8 deep to hide the L2 latency that
+    // dominates a 127-term dot product.
     double acc = 0.0;
+    const double* Ar = A + (long)i * n;
+    int k = 0;
     if (IN_GRID) {
-        const T* B = reinterpret_cast<const T*>(Bv);
-        for (int k = 0; k < n; ++k) acc += A[(long)i * n + k] * (double)B[(long)(k + 1) * gpitch + (j + 1)];
+        const T* B = reinterpret_cast<const T*>(Bv) + gpitch + (j + 1);
+        for (; k + 8 <= n; k += 8) {
+            double a[8], b[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { a[q] = Ar[k + q]; b[q] = (double)B[(long)(k + q) * gpitch]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += a[q] * b[q];
+        }
+        for (; k < n; ++k) acc += Ar[k] * (double)B[(long)k * gpitch];
     } else {
-        const double* B = reinterpret_cast<const double*>(Bv);
-        for (int k = 0; k < n; ++k) acc += A[(long)i * n + k] * B[(long)k * n + j];
+        const double* B = reinterpret_cast<const double*>(Bv) + j;
+        for (; k + 8 <= n; k += 8) {
+            double a[8], b[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { a[q] = Ar[k + q]; b[q] = B[(long)(k + q) * n]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += a[q] * b[q];
+        }
+        for (; k < n; ++k) acc += Ar[k] * B[(long)k * n];
     }
     if (SCALE) acc = acc / (s[i] + s[j]);
     if (OUT_GRID) reinterpret_cast<T*>(Cv)[(long)(i + 1) * gpitch + (j + 1)] = (T)acc;

@@ -628,6 +628,179 @@ k_prolong(T* __restrict__ v, const T* __restrict__ coarse, int N, long pitch, lo
     }
 }
 
+// =============================================================================
+// k_jacobi_cycle: k_jacobi_fused with the V-cycle's transfer operators folded
+// into the same pass over the finest data, so that v and b are not re-read for
+// them (single-GPU hierarchy: coarse row I sits on fine row 2I of the same grid):
+//   PRE  = 1 : the input row is  v + P e  (PS:620-624), e the coarse correction;
+//              the corrected v is consumed on the fly and never stored.
+//   POST = 1 : after the K-th sweep the residual b - A v (PS:604-607) of the new
+//              iterate is formed in registers and restricted (PS:531-546) into
+//              the coarse right-hand side; the coarse guess is zeroed (PS:613).
+//   POST = 2 : after the K-th sweep sum (b - A v)^2 over the chunk -> partial[]
+//              (the residual norm the solve loop reports after every cycle).
+// K >= 1.  Every stage performs the arithmetic of the stand-alone kernel it
+// replaces, in the same order: results are bit-identical (tests).
+// Needs XC = K + {0,2,1}[POST] halo columns per side and one extra level window.
+// =============================================================================
+template <int K, int POST> constexpr int cycle_halo_cols() { return K + (POST == 1 ? 2 : (POST == 2 ? 1 : 0)); }
+template <int K, int POST, int W> constexpr int cycle_out_lanes() { return kWave - 2 * ((cycle_halo_cols<K, POST>() + W - 1) / W); }
+
+template <typename T, int K, int PRE, int POST>
+__global__ void __launch_bounds__(kBlock)
+k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
+               const T* __restrict__ coarse_e,                       // PRE
+               T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,   // POST == 1
+               double* __restrict__ partial,                          // POST == 2
+               int N, long pitch, long cpitch, int row_lo, int row_hi, int R, int strips, int chunks, T c0, T c1)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int W = VecOf<T>::W;
+    constexpr int CW = W / 2;
+    constexpr int XC = cycle_halo_cols<K, POST>();
+    constexpr int HL = (XC + W - 1) / W;
+    constexpr int OUT = kWave - 2 * HL;
+    constexpr int ETOP = POST ? 1 : 0;
+    constexpr int EBOT = POST == 1 ? 2 : (POST == 2 ? 1 : 0);
+    __shared__ double wsum[kWavesPerBlock];
+    const Tile t = wave_tile(strips, chunks);
+    const int bnd_lo = 0, bnd_hi = N;
+    double acc = 0.0;
+    if (t.active) {
+        const int lane = threadIdx.x & 63;
+        const int vx = t.strip * OUT - HL + lane;
+        const long col = (long)vx * W;
+        const bool ld = (vx >= 0) && (col + W <= pitch);
+        const bool st = (lane >= HL) && (lane < kWave - HL) && (vx < N / W);
+        const int r0 = row_lo + t.chunk * R;
+        const int r1 = min(r0 + R, row_hi);
+        const T* pv = vin + col;
+        const T* pb = rhs + col;
+        T* po = vout + col;
+        const V Z = vzero((V*)nullptr);
+        const long ccol = col / 2;
+        const int NC = N / 2;
+        const bool cld = ld && (ccol + CW < cpitch);
+
+        V lev[K + 1][3];      // lev[j] = level-j rows (y-j-2, y-j-1, y-j); level K only when POST
+        V bw[K + 1];          // bw[j]  = rhs row y-1-j
+#pragma unroll
+        for (int j = 0; j <= K; ++j) { lev[j][0] = Z; lev[j][1] = Z; lev[j][2] = Z; bw[j] = Z; }
+        Trip<T> top[CW], mid[CW];
+#pragma unroll
+        for (int k = 0; k < CW; ++k) { top[k] = {(T)0, (T)0, (T)0}; mid[k] = {(T)0, (T)0, (T)0}; }
+
+        const int y_first = r0 - K - ETOP;
+        const int y_end = r1 + K + EBOT;            // exclusive
+        for (int y = y_first; y < y_end; ++y) {
+            const bool unk = (y > bnd_lo && y < bnd_hi);
+            V in = vload<V>(pv + (long)y * pitch, ld && y >= bnd_lo && y <= bnd_hi);
+            if (PRE) {
+                // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624)
+                const int I = y >> 1;
+                T a[CW + 1], b2[CW + 1], o[W];
+                const bool cl = cld && unk;
+                {
+                    const T* p = coarse_e + (long)I * cpitch + ccol;
+#pragma unroll
+                    for (int k = 0; k <= CW; ++k) a[k] = cl ? p[k] : (T)0;
+                }
+                if ((y & 1) == 0) {
+#pragma unroll
+                    for (int k = 0; k < CW; ++k) { o[2 * k] = a[k]; o[2 * k + 1] = (T)0.5 * (a[k] + a[k + 1]); }
+                } else {
+                    const T* p = coarse_e + (long)(I + 1) * cpitch + ccol;
+#pragma unroll
+                    for (int k = 0; k <= CW; ++k) b2[k] = cl ? p[k] : (T)0;
+#pragma unroll
+                    for (int k = 0; k < CW; ++k) {
+                        o[2 * k] = (T)0.5 * (a[k] + b2[k]);
+                        o[2 * k + 1] = (T)0.25 * (((a[k] + b2[k]) + a[k + 1]) + b2[k + 1]);
+                    }
+                }
+                V add;
+                if constexpr (W == 2) add = make_double2(o[0], o[1]);
+                else add = make_float4(o[0], o[1], o[2], o[3]);
+                mask_cols(add, col, N);
+                if constexpr (W == 2) { in.x = in.x + add.x; in.y = in.y + add.y; }
+                else { in.x = in.x + add.x; in.y = in.y + add.y; in.z = in.z + add.z; in.w = in.w + add.w; }
+            }
+            const V bn = vload<V>(pb + (long)(y - 1) * pitch,
+                                  ld && (y - 1) > bnd_lo && (y - 1) < bnd_hi && y >= y_first + 1);
+#pragma unroll
+            for (int j = K; j > 0; --j) bw[j] = bw[j - 1];
+            bw[0] = bn;
+            lev[0][0] = lev[0][1]; lev[0][1] = lev[0][2]; lev[0][2] = in;
+#pragma unroll
+            for (int j = 1; j <= K; ++j) {
+                const int row = y - j;
+                V o = jacobi_vec<T>(lev[j - 1][0], lev[j - 1][1], lev[j - 1][2], bw[j - 1], c0, c1);
+                mask_cols(o, col, N);
+                if (!(row > bnd_lo && row < bnd_hi)) o = Z;
+                if (j == K) vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);
+                if (j < K || POST) { lev[j][0] = lev[j][1]; lev[j][1] = lev[j][2]; lev[j][2] = o; }
+            }
+            if (POST) {
+                // residual of the new iterate on row rho = y-K-1 (rows rho-1, rho, rho+1 of level K)
+                const int rho = y - K - 1;
+                V res = residual_vec(lev[K][0], lev[K][1], lev[K][2], bw[K]);
+                mask_cols(res, col, N);
+                if (!(rho > bnd_lo && rho < bnd_hi)) res = Z;
+                if (POST == 2) {
+                    if (st && rho >= r0 && rho < r1) {
+                        if constexpr (W == 2) acc += (double)res.x * (double)res.x + (double)res.y * (double)res.y;
+                        else acc += ((double)res.x * (double)res.x + (double)res.y * (double)res.y) +
+                                    ((double)res.z * (double)res.z + (double)res.w * (double)res.w);
+                    }
+                } else {
+                    Trip<T> cur[CW];
+                    const T l = from_left(last(res));
+                    if constexpr (W == 2) { cur[0] = {l, res.x, res.y}; }
+                    else { cur[0] = {l, res.x, res.y}; cur[1] = {res.y, res.z, res.w}; }
+                    if (rho & 1) {
+                        // rho = 2I+1 closes coarse row I (top = 2I-1, mid = 2I, bot = cur)
+                        const int I = (rho - 1) >> 1;
+                        const bool emit = (2 * I >= r0) && (2 * I < r1) && I >= 1 && I < NC;
+                        T o[CW];
+#pragma unroll
+                        for (int k = 0; k < CW; ++k) {
+                            T corners = top[k].l + top[k].r; corners = corners + cur[k].l; corners = corners + cur[k].r;
+                            T edges = mid[k].l + mid[k].r; edges = edges + top[k].c; edges = edges + cur[k].c;
+                            o[k] = wgt * ((corners + (T)2 * edges) + (T)4 * mid[k].c);
+                            if (ccol + k == 0 || ccol + k >= NC) o[k] = (T)0;
+                        }
+                        if (st && emit) {
+                            T* pc = coarse_b + (long)I * cpitch + ccol;
+                            if constexpr (CW == 1) { pc[0] = o[0]; }
+                            else { *reinterpret_cast<float2*>(pc) = make_float2((float)o[0], (float)o[1]); }
+                            if (coarse_zero) {
+                                T* pz = coarse_zero + (long)I * cpitch + ccol;
+                                if constexpr (CW == 1) { pz[0] = (T)0; }
+                                else { *reinterpret_cast<float2*>(pz) = make_float2(0.f, 0.f); }
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < CW; ++k) top[k] = cur[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < CW; ++k) mid[k] = cur[k];
+                    }
+                }
+            }
+        }
+    }
+    if (POST == 2) {
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double sum = 0.0;
+            for (int w = 0; w < kWavesPerBlock; ++w) sum += wsum[w];
+            partial[blockIdx.x] = sum;
+        }
+    }
+}
+
 // mixed precision (config 5): u64 += scale * (double) e32, rows [row_lo,row_hi)
 __global__ void __launch_bounds__(kBlock)
 k_axpy_f32_to_f64(double* __restrict__ u, const float* __restrict__ e, double scale, int N, long pitch, long epitch,

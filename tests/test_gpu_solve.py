@@ -190,3 +190,23 @@ def test_config1_parameters_at_8192_jacobi_v1010(pkg):
     assert st.converged and 5 <= st.cycles <= 7            # 6 at every size
     n = float((1 << 13) - 1)
     assert st.fine_updates == 20.0 * st.cycles * n * n
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("mu1,mu2", [(10, 10), (2, 1), (1, 1), (5, 3), (3, 0), (6, 8)])
+def test_folded_cycle_passes_are_bit_identical(pkg, po, monkeypatch, dtype, mu1, mu2):
+    """k_jacobi_cycle (correction on load, residual+restriction and ||r||^2 appended to the
+    smoother passes) must give the bits of the stand-alone kernels, and both must match the oracle"""
+    cfg = dict(finest_level=11, coarsest_level=8, mu1=mu1, mu2=mu2, schedule=0, dtype=dtype)
+    b = po.rhs_sine(11)
+    u0 = po.fill_uniform(b.shape, 99)
+    out = {}
+    for fold in ("0", "1"):
+        monkeypatch.setenv("MGX_FOLD", fold)
+        st, h, u = run_gpu(pkg, cfg, b, u0, tol=0.0, max_cycles=3)
+        out[fold] = (h, u)
+    assert np.array_equal(out["0"][1], out["1"][1])
+    assert np.allclose(out["0"][0], out["1"][0], rtol=1e-13, atol=0)
+    if dtype == 1:
+        _, h_ref = po.Solver(**cfg).solve(b, u0, tol=0.0, max_cycles=3)
+        assert hist_close(out["1"][0], h_ref), (out["1"][0], h_ref)
