@@ -18,7 +18,10 @@ inside the time but only fine-grid updates are counted.
 N = 1 : one process, libmgx (C-ABI) through ctypes, HIP events for the roofline.
 N > 1 : one process per GPU (torch.distributed over RCCL), the finest levels
         slab-decomposed by rows with halo exchange between smoothing blocks
-        (multigrid_nikhil_c-_amd/dist.py); same problem at every N (strong scaling).
+        (multigrid_nikhil_c-_amd/dist.py).  Default grid 16384^2 (BASELINE config 4,
+        the north star's strong-scaling grid), the same at every N > 1; rank 0 also
+        times the single-GPU solver on that same grid inside the job and reports it
+        (`single_gpu_same_workload`) so the strong-scaling factor is like for like.
 """
 from __future__ import annotations
 
@@ -52,7 +55,9 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--level", type=int, default=13, help="finest level L: grid 2^L (8192^2 = BASELINE metric)")
+    p.add_argument("--level", type=int, default=None,
+                   help="finest level L: grid 2^L.  Default 13 (8192^2, BASELINE's metric grid) on one GPU, "
+                        "14 (16384^2, BASELINE config 4) on several")
     p.add_argument("--coarsest", type=int, default=7, help="coarsest level (PS:18)")
     p.add_argument("--mu1", type=int, default=10, help="pre-smoothing sweeps (PS:21)")
     p.add_argument("--mu2", type=int, default=10, help="post-smoothing sweeps (PS:22)")
@@ -252,8 +257,12 @@ def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus <= 1 and world <= 1:
+        if args.level is None:
+            args.level = 13
         run_single(args)
         return
+    if args.level is None:
+        args.level = 14
     from importlib import import_module
 
     import __graft_entry__ as ge

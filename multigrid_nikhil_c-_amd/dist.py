@@ -15,10 +15,15 @@ Communication plan (halo messages are latency-bound, so send few):
     exchanged ONCE; sweep k then updates a range that shrinks by one row per
     sweep at each interior slab edge (mgx_slab_jacobi(..., shrink=1)),
     recomputing the neighbour's rows redundantly instead of talking per sweep.
-  * per level and cycle: u halos before pre-smoothing (finest level only - the
-    coarse guesses are zero, halos included), 2 rows before the fused
-    residual+restriction, the restricted right-hand side's halo rows, 1 coarse
-    row before prolongation, mu2 rows before post-smoothing.
+  * redundant rows instead of messages: pre-smoothing is carried out on the owned
+    rows plus the rows the restriction (2) and the post-smoothing (mu2) will
+    need, and the correction is prolongated onto that extended range as well,
+    so neither the restriction nor the post-smoothing needs an exchange.
+  * what is left per cycle: ONE exchange of u on the finest level (it serves the
+    residual norm and the next pre-smoothing), and per distributed coarse level
+    one exchange of the restricted right-hand side and one shallow exchange of
+    the correction before it is prolongated (coarse guesses are zero, halos
+    included, so they need none).
   * one all_gather of the restricted residual at the cut-over level, one
     all_reduce of a double for ||r||^2.
 
@@ -181,7 +186,11 @@ class DistMultigrid:
         if finest_level <= cut_level:
             raise ValueError("finest_level must be above cut_level (otherwise use the single-GPU handle)")
         per_sweep = 2 if smoother == "rbgs" else 1
-        self.halo = max(per_sweep * max(mu1, mu2), 2)
+        self.per = per_sweep
+        self.ext_post = per_sweep * mu2               # halo rows the post-smoothing consumes
+        self.ext_keep = max(self.ext_post, 2)         # rows beyond the owned ones pre-smoothing leaves valid
+        self.ext_coarse = self.ext_post // 2 + 2      # coarse halo rows the extended prolongation reads
+        self.halo = max(per_sweep * mu1 + self.ext_keep, self.ext_coarse)
         self.lv = {}
         for l in range(cut_level + 1, finest_level + 1):
             N = 1 << l
@@ -246,26 +255,33 @@ class DistMultigrid:
         self.exchanges += 1
 
     # ---- operators -------------------------------------------------------------------
-    def _smooth(self, L, mu):
+    def _range(self, L, ext):
+        """owned unknown rows widened by `ext` rows into the halos (local indices)"""
+        first, last = 1 - L.row0, L.N - L.row0
+        return max(L.upd_lo - ext, first), min(L.upd_hi + ext, last)
+
+    def _smooth(self, L, mu, keep):
+        """mu sweeps whose result is valid on the owned rows +- keep"""
         if mu <= 0:
             return
-        need = (2 if self.smoother == "rbgs" else 1) * mu
+        need = self.per * mu + keep
         if L.u_halo < need:
-            self.exchange(L, L.u, need)
+            self.exchange(L, L.u, L.halo)
+            L.u_halo = L.halo
+        lo, hi = self._range(L, keep)
         timed = self.profile and L.level == self.Lf and L.u.is_cuda
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        L.u, L.tmp = self.ops.smooth(self.smoother, L.level, L.row0, L.u, L.b, L.tmp, L.upd_lo, L.upd_hi, mu,
-                                     self.omega, shrink=True)
+        L.u, L.tmp = self.ops.smooth(self.smoother, L.level, L.row0, L.u, L.b, L.tmp, lo, hi, mu, self.omega,
+                                     shrink=True)
         if timed:
             e1.record()
-            per = 2 if self.smoother == "rbgs" else 1
             first, last = 1 - L.row0, L.N - L.row0
-            rows = sum(min(L.upd_hi + per * (mu - 1 - k), last) - max(L.upd_lo - per * (mu - 1 - k), first)
+            rows = sum(min(hi + self.per * (mu - 1 - k), last) - max(lo - self.per * (mu - 1 - k), first)
                        for k in range(mu))
             self._events.append((e0, e1, rows * (L.N - 1) * 3 * L.u.element_size(), mu))
-        L.u_halo = 0
+        L.u_halo = keep
         if L.level == self.Lf:
             self.fine_updates += float(mu) * (L.N - 1) * (L.N - 1)
 
@@ -278,12 +294,14 @@ class DistMultigrid:
         """PS:575-627 on the slab hierarchy, from `level` (default: finest) down"""
         l = self.Lf if level is None else level
         L = self.lv[l]
-        self._smooth(L, self.mu1)                                                       # PS:581
-        if L.u_halo < 2:
-            self.exchange(L, L.u, 2)
-            L.u_halo = 2
+        if self.mu1 > 0:
+            self._smooth(L, self.mu1, self.ext_keep)                                    # PS:581
+        elif L.u_halo < self.ext_keep:
+            self.exchange(L, L.u, L.halo)
+            L.u_halo = L.halo
         NC = L.N // 2
         glo, ghi = self._own_coarse_rows(NC)
+        plo, phi = self._range(L, self.ext_post)          # fine rows that receive the correction
         if l - 1 > self.Lcut:
             Cl = self.lv[l - 1]
             Cl.u.zero_()                                                                # PS:613
@@ -292,10 +310,10 @@ class DistMultigrid:
             self.exchange(Cl, Cl.b, Cl.halo)
             Cl.u_halo = Cl.halo                        # zeros are exact halo values
             self.vcycle(l - 1)                                                          # PS:617
-            if Cl.u_halo < 1:
-                self.exchange(Cl, Cl.u, 1)
-                Cl.u_halo = 1
-            self.ops.prolong(l, L.row0, L.u, Cl.row0, Cl.u, L.upd_lo, L.upd_hi, add=True)   # PS:620-624
+            if Cl.u_halo < self.ext_coarse:
+                self.exchange(Cl, Cl.u, self.ext_coarse)
+                Cl.u_halo = self.ext_coarse
+            self.ops.prolong(l, L.row0, L.u, Cl.row0, Cl.u, plo, phi, add=True)         # PS:620-624
         else:
             self.ops.restrict(l, L.row0, L.u, L.b, self.c_row0, self.c_own, None, glo - self.c_row0,
                               ghi - self.c_row0, self.restrict_mode, fused=True)
@@ -310,17 +328,18 @@ class DistMultigrid:
             else:
                 self.c_b[:NC].copy_(self.c_own)
             self.coarse.vcycle_from_zero(self.c_b, self.c_e)                            # levels cut..coarsest
-            self.ops.prolong(l, L.row0, L.u, 0, self.c_e, L.upd_lo, L.upd_hi, add=True)
-        L.u_halo = 0
-        self._smooth(L, self.mu2)                                                       # PS:625
+            self.ops.prolong(l, L.row0, L.u, 0, self.c_e, plo, phi, add=True)
+        L.u_halo = min(L.u_halo, self.ext_post)
+        self._smooth(L, self.mu2, 0)                                                    # PS:625
+        if self.mu2 <= 0:
+            L.u_halo = 0
 
     def residual_norm(self):
         """||b - A u||_2 on the finest level (all ranks get the value)"""
         L = self.lv[self.Lf]
-        need = max(1, (2 if self.smoother == "rbgs" else 1) * self.mu1)
         if L.u_halo < 1:
-            self.exchange(L, L.u, need)          # deep enough for the next pre-smoothing too
-            L.u_halo = need
+            self.exchange(L, L.u, L.halo)        # deep enough for the next pre-smoothing too
+            L.u_halo = L.halo
         s = self.ops.sumsq(self.Lf, L.row0, L.u, L.b, L.upd_lo, L.upd_hi)
         if self.P > 1:
             if self.staged:

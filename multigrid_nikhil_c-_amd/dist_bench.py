@@ -35,12 +35,35 @@ def _rhs_sine(rows, cols, N):
 
 
 def default_cut(finest, coarsest, world, halo):
-    """two distributed levels: below that a replicated level is cheaper than the
-    halo exchanges a distributed one costs (DESIGN.md "Multi-GPU")"""
-    cut = max(coarsest, finest - 2)
-    while cut < finest - 1 and ((1 << (cut + 1)) // world) < halo:
+    """levels up to 2048^2 are replicated: below that a replicated level costs
+    less than the exchanges a distributed one needs (DESIGN.md "Multi-GPU")"""
+    cut = max(coarsest, min(finest - 2, 11))
+    while cut < finest - 1 and ((1 << (cut + 1)) // world) < 2 * halo:
         cut += 1
     return cut
+
+
+def single_gpu_reference(args, L, steps):
+    """rank 0 only: the same workload on ONE GPU through the ordinary handle
+    (untimed part of the job; gives the like-for-like strong-scaling baseline)"""
+    import time as _t
+
+    mg = B.Multigrid(finest_level=L, coarsest_level=min(args.coarsest, L), mu0=0, mu1=args.mu1, mu2=args.mu2,
+                     omega=args.omega, smoother=B.SMOOTHER_RBGS if args.smoother == "rbgs" else B.SMOOTHER_JACOBI,
+                     dtype=B.DTYPE_F32 if args.dtype == "f32" else B.DTYPE_F64, schedule=B.SCHEDULE_V,
+                     device=torch.cuda.current_device())
+    try:
+        mg.fill_rhs(1, 0.0)
+        mg.fill_guess_random(12345)
+        mg.solve(tol=0.0, max_cycles=1)
+        mg.synchronize()
+        t0 = _t.perf_counter()
+        st, _ = mg.solve(tol=0.0, max_cycles=steps)
+        mg.synchronize()
+        secs = _t.perf_counter() - t0
+        return {"value": st.fine_updates / secs, "unit": "updates/s", "ms_per_step": secs / steps * 1e3, "steps": steps}
+    finally:
+        mg.close()
 
 
 def run(args, emit=None):
@@ -55,8 +78,12 @@ def run(args, emit=None):
     if args.dtype == "mixed":
         raise SystemExit("--dtype mixed is a single-GPU configuration in this round")
     per = 2 if args.smoother == "rbgs" else 1
-    halo = max(per * max(args.mu1, args.mu2), 2)
+    halo = per * args.mu1 + max(per * args.mu2, 2)
     L = args.level
+    ref = None
+    if rank == 0 and world > 1:
+        ref = single_gpu_reference(args, L, max(1, min(args.steps, 5)))
+    torch.cuda.synchronize()
     cut = default_cut(L, args.coarsest, world, halo)
     cfg = dict(mu1=args.mu1, mu2=args.mu2, omega=args.omega, smoother=args.smoother,
                restrict_mode=B.RESTRICT_CONSISTENT, bottom=B.BOTTOM_EXACT)
@@ -114,17 +141,20 @@ def run(args, emit=None):
             "config": {
                 "workload": f"2D Poisson {1 << L}^2 (n={n} interior), {L - min(args.coarsest, cut) + 1}-level V({args.mu1},{args.mu2}) cycle, "
                             f"{'weighted Jacobi w=%.4f' % args.omega if args.smoother == 'jacobi' else 'red-black Gauss-Seidel'}, "
-                            f"{args.dtype}, row slabs over {world} GPUs on levels {cut + 1}..{L} ({halo}-row deep halos, RCCL "
+                            f"{args.dtype}, row slabs over {world} GPUs on levels {cut + 1}..{L} ({mg.halo}-row deep halos, RCCL "
                             f"send/recv), levels <= {cut} replicated, exact bottom solve at {(1 << min(args.coarsest, cut)) - 1}^2",
                 "finest_level": L, "coarsest_level": min(args.coarsest, cut), "cut_level": cut, "mu1": args.mu1,
                 "mu2": args.mu2, "smoother": args.smoother, "step": "one V-cycle + residual norm",
                 "parallelism": f"slab{world}",
             },
             "vcycles_to_1e-8": k_tol if hist0[-1] <= 1e-8 * hist0[0] else None,
+            "single_gpu_same_workload": ref,
+            "speedup_vs_single_gpu_same_workload": (mg.fine_updates / secs / ref["value"]) if ref else None,
             "halo_exchanges_per_step": mg.exchanges_timed / max(args.steps, 1),
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("k_rbgs" if args.smoother == "rbgs" else "k_jacobi_rows") + ("<double>" if es == 8 else "<float>"),
+                "kernel": ("k_rbgs<%s>" if args.smoother == "rbgs" else "k_jacobi_fused<%s,K> (slab rows, deep halos)")
+                          % ("double" if es == 8 else "float"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "how": "rank 0: torch.cuda events (current stream = the kernels' stream) around every finest-level "
