@@ -156,24 +156,69 @@ void launch_jacobi(const T* vin, const T* b, T* vout, int N, long pitch, int row
                        row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1);
 }
 
-// K sweeps in one pass (k_jacobi_fused); K in 2..5
-template <typename T, int K>
-void launch_jacobi_fused_k(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
-                           T c0, T c1, int bnd_lo, int bnd_hi, int R, hipStream_t st)
+template <typename T>
+void launch_rbgs(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
+                 int row_parity, int bnd_lo, int bnd_hi, int rpc, hipStream_t st)
+{
+    if (row_hi <= row_lo) return;
+    const Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, rpc);
+    hipLaunchKernelGGL((k_rbgs<T>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
+                       row_lo, row_hi, g.R, g.strips, g.chunks, row_parity, bnd_lo, bnd_hi);
+}
+
+// K levels in one pass (k_jacobi_fused<T,K,SM>): K Jacobi sweeps (SM = 0) or K/2
+// red-black Gauss-Seidel sweeps (SM = 1)
+template <typename T, int K, int SM>
+void launch_fused_k(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
+                    T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st)
 {
     constexpr int OUT = fused_out_lanes<K, VecOf<T>::W>();
     Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, R);
     g.strips = (N / VecOf<T>::W + OUT - 1) / OUT;
     const long waves = (long)g.strips * g.chunks;
     g.blocks = (int)(((waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
-    hipLaunchKernelGGL((k_jacobi_fused<T, K>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
-                       row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, bnd_lo, bnd_hi);
+    hipLaunchKernelGGL((k_jacobi_fused<T, K, SM>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
+                       row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, bnd_lo, bnd_hi, row_parity);
+}
+
+template <typename T, int SM>
+bool launch_fused(int K, const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
+                  T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st)
+{
+    switch (K) {
+        case 2: launch_fused_k<T, 2, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
+        case 4: launch_fused_k<T, 4, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
+        case 6: launch_fused_k<T, 6, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
+        case 8: launch_fused_k<T, 8, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
+        case 10: launch_fused_k<T, 10, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
+        default: break;
+    }
+    if constexpr (SM == 0) {
+        switch (K) {
+            case 3: launch_fused_k<T, 3, 0>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
+            case 5: launch_fused_k<T, 5, 0>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
+            default: break;
+        }
+    }
+    return false;
+}
+
+// chunk height of a fused pass: shallow passes (K <= 3 levels) want many short
+// chunks, deep ones want tall chunks to amortise their 2K redundant rows (measured)
+inline int fuse_rows(const FuseCfg& fc, int N, int K)
+{
+    if (fc.rows > 0) return fc.rows;
+    if (K <= 3) return 8;
+    int R = N / 128;
+    if (R < 8) R = 8;
+    if (R > 64) R = 64;
+    return R;
 }
 
 inline FuseCfg fuse_cfg()
 {
     FuseCfg f;
-    f.kmax = env_int("MGX_FUSE", 10);          // 1 disables temporal fusion
+    f.kmax = env_int("MGX_FUSE", 10);          // levels per pass; 1 disables temporal fusion
     if (f.kmax < 1) f.kmax = 1;
     if (f.kmax > 10) f.kmax = 10;
     f.rows = env_int("MGX_FUSE_ROWS", 0);      // 0: chosen from the grid size
@@ -181,23 +226,28 @@ inline FuseCfg fuse_cfg()
     return f;
 }
 
-// Per-sweep throughput of k_jacobi_fused<T,K> relative to K = 1, measured on
-// MI355X at 8192^2 (tools/microbench, profiles/r01_fused_microbench.md).  0 = not
-// instantiated.  K = 5 is poor in float because it needs a second halo lane per
-// side for one extra column; K = 8 uses both lanes fully.
+// Per-sweep throughput of a fused launch relative to one stand-alone sweep,
+// measured on MI355X at 8192^2 (tools/microbench, profiles/r01_fused_microbench.md).
+// Index = sweeps per launch; 0 = not instantiated.  Jacobi: K = 5 is poor in
+// float because it needs a second halo lane per side for one extra column.
 constexpr double kFuseRate64[11] = {0, 1.00, 1.72, 2.52, 3.37, 4.11, 4.45, 0, 4.15, 0, 3.78};
 constexpr double kFuseRate32[11] = {0, 1.00, 1.65, 2.42, 3.13, 2.66, 3.60, 0, 3.89, 0, 3.24};
+// red-black Gauss-Seidel: s sweeps = 2 s levels, s <= 5
+constexpr double kFuseRateGS64[11] = {0, 1.00, 1.83, 2.45, 2.50, 2.12, 0, 0, 0, 0, 0};
+constexpr double kFuseRateGS32[11] = {0, 1.00, 1.81, 2.10, 2.45, 1.86, 0, 0, 0, 0, 0};
 
 // split mu sweeps into fused launches minimising the modelled time; parts[] gets
-// the K of each launch, returns their count
-inline int plan_fusion(int mu, int kmax, bool f64, int* parts)
+// the sweeps of each launch, returns their count.  kmax bounds the LEVELS per pass.
+inline int plan_fusion(int mu, int kmax, bool f64, int* parts, bool rbgs = false)
 {
-    const double* rate = f64 ? kFuseRate64 : kFuseRate32;
+    const double* rate = rbgs ? (f64 ? kFuseRateGS64 : kFuseRateGS32) : (f64 ? kFuseRate64 : kFuseRate32);
+    const int per = rbgs ? 2 : 1;
+    const int smax = std::max(1, std::min(kmax, 10) / per);
     std::vector<double> best(mu + 1, 1e300);
     std::vector<int> pick(mu + 1, 1);
     best[0] = 0.0;
     for (int m = 1; m <= mu; ++m)
-        for (int k = 1; k <= std::min(m, std::min(kmax, 10)); ++k) {
+        for (int k = 1; k <= std::min(m, smax); ++k) {
             if (rate[k] <= 0.0) continue;
             // + a small per-launch cost so that equal-rate splits prefer fewer launches
             const double c = best[m - k] + (double)k / rate[k] + 0.02;
@@ -208,16 +258,18 @@ inline int plan_fusion(int mu, int kmax, bool f64, int* parts)
     return n;
 }
 
-// mu Jacobi sweeps on rows [row_lo,row_hi) ping-ponging a <-> b2; returns the number
-// of launches' parity (1: result is in `b2`).  first/last: unknown rows are
-// (first-1, last) exclusive bounds, i.e. bnd_lo = first-1 and bnd_hi = last.
-// shrink: deep-halo mode, sweep k covers [row_lo-(mu-1-k), row_hi+(mu-1-k)) clipped.
-// rows_alloc: rows in the arrays (bounds are validated, never assumed).
+// mu smoother sweeps on rows [row_lo,row_hi) ping-ponging a <-> b2; *parity = 1 when
+// the result ends in `b2`.  Unknown rows are [first, last) (so the global
+// boundary rows are first-1 and last).  shrink: deep-halo mode, the sweeps still
+// to come after a launch widen its range by `per` rows each at every interior
+// edge.  rows_alloc bounds every row that is read (validated, never assumed).
 template <typename T>
-int jacobi_block(T* a, const T* rhs, T* b2, int N, long pitch, int rows_alloc, int row_lo, int row_hi, int mu,
-                 double omega, bool shrink, int first, int last, int rpc, const FuseCfg& fc, hipStream_t st, int* parity,
-                 int* launches = nullptr)
+int smooth_block(int smoother, T* a, const T* rhs, T* b2, int N, long pitch, int rows_alloc, int row_lo, int row_hi,
+                 int mu, double omega, bool shrink, int first, int last, int row_parity, int rpc, const FuseCfg& fc,
+                 hipStream_t st, int* parity, int* launches = nullptr)
 {
+    const bool rbgs = (smoother == MGX_SMOOTHER_RBGS);
+    const int per = rbgs ? 2 : 1;
     const T om = (T)omega;
     const T c0 = (T)(1.0 - (double)om);
     const T c1 = (T)((double)om / 4.0);
@@ -226,36 +278,33 @@ int jacobi_block(T* a, const T* rhs, T* b2, int N, long pitch, int rows_alloc, i
     int done = 0;
     // Fused launches pay (R + 2K)/R redundant rows and need enough chunks to fill
     // the chip: measured worthwhile from 1024^2 up, with R growing with the grid.
-    const bool allow_fuse = fc.kmax > 1 && N >= 1024 && (row_hi - row_lo) >= 64;
-    int R = fc.rows;
-    if (R <= 0) { R = N / 128; if (R < 8) R = 8; if (R > 64) R = 64; }
+    const bool allow_fuse = fc.kmax > per && N >= 1024 && (row_hi - row_lo) >= 64 && mu <= 64;
     std::vector<int> parts(mu > 0 ? mu : 1, 1);
-    const int nparts = allow_fuse ? plan_fusion(mu, fc.kmax, sizeof(T) == 8, parts.data()) : mu;
+    const int nparts = allow_fuse ? plan_fusion(mu, fc.kmax, sizeof(T) == 8, parts.data(), rbgs) : mu;
+    const int bl = first - 1, bh = last;
     for (int p = 0; p < nparts; ++p) {
-        const int k = allow_fuse ? parts[p] : 1;
-        const int after = mu - (done + k);                       // sweeps still to come after this launch
-        const int ext = shrink ? after : 0;
+        const int sw = allow_fuse ? parts[p] : 1;               // sweeps in this launch
+        const int K = per * sw;                                  // levels in this launch
+        const int ext = shrink ? per * (mu - (done + sw)) : 0;   // rows the later launches still consume
         const int lo = std::max(row_lo - ext, first), hi = std::min(row_hi + ext, last);
         if (hi > lo) {
-            // rows read: [lo-k, hi+k) clipped to the global boundary rows
-            const int rd_lo = std::max(lo - k, first - 1), rd_hi = std::min(hi + k - 1, last);
+            // rows read: [lo-K, hi+K) clipped to the global boundary rows
+            const int rd_lo = std::max(lo - K, bl), rd_hi = std::min(hi + K - 1, bh);
             if (rd_lo < 0 || rd_hi > rows_alloc - 1) return MGX_ERR_INVALID;
-            const int bl = first - 1, bh = last;
-            switch (k) {
-                case 1: launch_jacobi<T>(src, rhs, dst, N, pitch, lo, hi, omega, rpc, st); break;
-                case 2: launch_jacobi_fused_k<T, 2>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
-                case 3: launch_jacobi_fused_k<T, 3>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
-                case 4: launch_jacobi_fused_k<T, 4>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
-                case 5: launch_jacobi_fused_k<T, 5>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
-                case 6: launch_jacobi_fused_k<T, 6>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
-                case 8: launch_jacobi_fused_k<T, 8>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
-                case 10: launch_jacobi_fused_k<T, 10>(src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, R, st); break;
-                default: return MGX_ERR_INVALID;
+            if (!rbgs && sw == 1) {
+                launch_jacobi<T>(src, rhs, dst, N, pitch, lo, hi, omega, rpc, st);
+            } else if (rbgs && !allow_fuse) {
+                launch_rbgs<T>(src, rhs, dst, N, pitch, lo, hi, row_parity, bl, bh, rpc, st);
+            } else {
+                const int R = fuse_rows(fc, N, K);
+                const bool ok = rbgs ? launch_fused<T, 1>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st)
+                                     : launch_fused<T, 0>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st);
+                if (!ok) return MGX_ERR_INVALID;
             }
         }
         std::swap(src, dst);
         ++flips;
-        done += k;
+        done += sw;
     }
     *parity = flips & 1;
     if (launches) *launches = flips;
@@ -272,7 +321,7 @@ struct FoldArgs {
     long cpitch = 0;
 };
 
-template <typename T, int K, int PRE, int POST>
+template <typename T, int K, int PRE, int POST, int SM>
 int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N, long pitch, T c0, T c1, int R,
                    hipStream_t st)
 {
@@ -283,39 +332,36 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
     const long waves = (long)g.strips * g.chunks;
     g.blocks = (int)(((waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
-    hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout,
+    hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout,
                        (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
                        1, N, g.R, g.strips, g.chunks, c0, c1);
     return g.blocks;
 }
 
-template <typename T, int PRE, int POST>
+template <typename T, int PRE, int POST, int SM>
 int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, int N, long pitch, T c0, T c1, int R,
                  hipStream_t st)
 {
     switch (K) {
-        case 1: return launch_cycle_k<T, 1, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
-        case 2: return launch_cycle_k<T, 2, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
-        case 3: return launch_cycle_k<T, 3, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
-        case 4: return launch_cycle_k<T, 4, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
-        case 5: return launch_cycle_k<T, 5, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
-        case 6: return launch_cycle_k<T, 6, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
-        case 8: return launch_cycle_k<T, 8, PRE, POST>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
-        default: return -1;
+        case 2: return launch_cycle_k<T, 2, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        case 4: return launch_cycle_k<T, 4, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        case 6: return launch_cycle_k<T, 6, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        case 8: return launch_cycle_k<T, 8, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        default: break;
     }
+    if constexpr (SM == 0) {
+        switch (K) {
+            case 1: return launch_cycle_k<T, 1, PRE, POST, 0>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+            case 3: return launch_cycle_k<T, 3, PRE, POST, 0>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+            case 5: return launch_cycle_k<T, 5, PRE, POST, 0>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+            default: break;
+        }
+    }
+    return -1;
 }
 
-inline bool cycle_k_supported(int K) { return K >= 1 && K <= 8 && K != 7; }
-
-template <typename T>
-void launch_rbgs(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
-                 int row_parity, int bnd_lo, int bnd_hi, int rpc, hipStream_t st)
-{
-    if (row_hi <= row_lo) return;
-    const Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, rpc);
-    hipLaunchKernelGGL((k_rbgs<T>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
-                       row_lo, row_hi, g.R, g.strips, g.chunks, row_parity, bnd_lo, bnd_hi);
-}
+// levels per pass the folded kernels are instantiated for
+inline bool cycle_k_supported(int K, bool rbgs) { return rbgs ? (K == 2 || K == 4 || K == 6 || K == 8) : (K >= 1 && K <= 8 && K != 7); }
 
 template <typename T>
 void launch_restrict(const T* v, const T* b, T* cb, T* czero, int N, long pitch, long cpitch,
@@ -473,18 +519,9 @@ int copy_out(mgx_solver* s, Level& l, const void* src_grid, void* dst, size_t co
 template <typename T>
 void smooth_t(mgx_solver* s, Level& l, int mu)
 {
-    const int rpc = s->rows_per_chunk;
-    if (s->cfg.smoother == MGX_SMOOTHER_RBGS) {
-        for (int k = 0; k < mu; ++k) {
-            launch_rbgs<T>((const T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, 1, l.N, 0, 0, l.N, rpc, s->stream);
-            std::swap(l.u, l.tmp);
-        }
-        s->last_smooth_launches = mu;
-        return;
-    }
     int parity = 0, launches = 0;
-    (void)jacobi_block<T>((T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, l.rows, 1, l.N, mu, s->cfg.omega, false,
-                          1, l.N, rpc, s->fuse, s->stream, &parity, &launches);
+    (void)smooth_block<T>(s->cfg.smoother, (T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, l.rows, 1, l.N, mu,
+                          s->cfg.omega, false, 1, l.N, 0, s->rows_per_chunk, s->fuse, s->stream, &parity, &launches);
     s->last_smooth_launches = launches;
     if (parity) std::swap(l.u, l.tmp);
 }
@@ -494,22 +531,17 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
 // (post = 1) or the residual norm (post = 2) produced by the last pass.
 // Returns false when this level / configuration is not eligible (caller then
 // uses the stand-alone kernels); on success *norm_blocks = partial sums written.
-template <typename T>
+template <typename T, int SM>
 bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool pre, int post, int* launches,
                      int* norm_blocks)
 {
-    if (!s->fold || s->cfg.smoother != MGX_SMOOTHER_JACOBI || mu < 1 || l.N < 1024 || s->fuse.kmax < 1) return false;
+    constexpr bool rbgs = (SM == 1);
+    constexpr int per = rbgs ? 2 : 1;
     int parts[64];
-    if (mu > 64) return false;
-    const int kmax = std::min(s->fuse.kmax, 8);
-    const int np = plan_fusion(mu, kmax, sizeof(T) == 8, parts);
-    for (int p = 0; p < np; ++p)
-        if (!cycle_k_supported(parts[p])) return false;
+    const int np = plan_fusion(mu, std::min(s->fuse.kmax, 8), sizeof(T) == 8, parts, rbgs);
     const T om = (T)s->cfg.omega;
     const T c0 = (T)(1.0 - (double)om);
     const T c1 = (T)((double)om / 4.0);
-    int R = s->fuse.rows;
-    if (R <= 0) { R = l.N / 128; if (R < 8) R = 8; if (R > 64) R = 64; }
     FoldArgs fa;
     fa.restrict_mode = s->cfg.restrict_mode;
     fa.partial = s->partial;
@@ -520,34 +552,16 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
         const bool first = (p == 0), last = (p == np - 1);
         const bool P = pre && first;
         const int Q = last ? post : 0;
+        const int K = per * parts[p];
+        const int R = fuse_rows(s->fuse, l.N, K);
         int blocks = 0;
-        if (P && Q == 2) blocks = launch_cycle<T, 1, 2>(parts[p], src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
-        else if (P && Q == 1) return false;   // never requested
-        else if (P) blocks = launch_cycle<T, 1, 0>(parts[p], src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
-        else if (Q == 1) blocks = launch_cycle<T, 0, 1>(parts[p], src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
-        else if (Q == 2) blocks = launch_cycle<T, 0, 2>(parts[p], src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
-        else {
-            const int k = parts[p];
-            if (k == 1) launch_jacobi<T>(src, b, dst, l.N, l.pitch, 1, l.N, s->cfg.omega, s->rows_per_chunk, s->stream);
-            else {
-                int par = 0;
-                FuseCfg one = s->fuse; one.kmax = k;
-                // a single plain fused launch of exactly k sweeps
-                switch (k) {
-                    case 2: launch_jacobi_fused_k<T, 2>(src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, R, s->stream); break;
-                    case 3: launch_jacobi_fused_k<T, 3>(src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, R, s->stream); break;
-                    case 4: launch_jacobi_fused_k<T, 4>(src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, R, s->stream); break;
-                    case 5: launch_jacobi_fused_k<T, 5>(src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, R, s->stream); break;
-                    case 6: launch_jacobi_fused_k<T, 6>(src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, R, s->stream); break;
-                    default: launch_jacobi_fused_k<T, 8>(src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, R, s->stream); break;
-                }
-                (void)par; (void)one;
-            }
-        }
-        if (Q == 2) {
-            if (blocks < 0 || blocks > s->partial_cap) return false;   // cannot happen: checked below before launch
-            *norm_blocks = blocks;
-        }
+        if (P && Q == 2) blocks = launch_cycle<T, 1, 2, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
+        else if (P) blocks = launch_cycle<T, 1, 0, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
+        else if (Q == 1) blocks = launch_cycle<T, 0, 1, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
+        else if (Q == 2) blocks = launch_cycle<T, 0, 2, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
+        else if (!rbgs && K == 1) launch_jacobi<T>(src, b, dst, l.N, l.pitch, 1, l.N, s->cfg.omega, s->rows_per_chunk, s->stream);
+        else (void)launch_fused<T, SM>(K, src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, 0, R, s->stream);
+        if (Q == 2) *norm_blocks = blocks;
         std::swap(src, dst);
     }
     if (np & 1) std::swap(l.u, l.tmp);
@@ -555,14 +569,18 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
     return true;
 }
 
-// pre-check used before any launch is made (so a `false` never leaves a half-done block)
+// pre-check made before any launch (so a `false` never leaves a half-done block)
 bool fold_eligible(const mgx_solver* s, const Level& l, int mu)
 {
-    if (!s->fold || s->cfg.smoother != MGX_SMOOTHER_JACOBI || mu < 1 || mu > 64 || l.N < 1024) return false;
+    if (!s->fold || mu < 1 || mu > 64 || l.N < 1024) return false;
+    const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
+    const int per = rbgs ? 2 : 1;
+    if (s->fuse.kmax < per) return false;
     int parts[64];
-    const int np = plan_fusion(mu, std::min(s->fuse.kmax, 8), l.f64, parts);
+    const int np = plan_fusion(mu, std::min(s->fuse.kmax, 8), l.f64, parts, rbgs);
     for (int p = 0; p < np; ++p)
-        if (!cycle_k_supported(parts[p])) return false;
+        if (!cycle_k_supported(per * parts[p], rbgs)) return false;
+    // the norm partials of the folded pass must fit the reduction buffer
     return true;
 }
 
@@ -574,8 +592,12 @@ bool smooth_folded(mgx_solver* s, int level, int mu, bool pre, int post)
     const bool fine = (level == s->cfg.finest_level);
     Prof p(s, fine ? MGX_PROF_SMOOTH_FINE : MGX_PROF_COARSE, mu);
     int launches = 0, nb = 0;
-    const bool ok = l.f64 ? smooth_folded_t<double>(s, l, mu, coarse, pre, post, &launches, &nb)
-                          : smooth_folded_t<float>(s, l, mu, coarse, pre, post, &launches, &nb);
+    const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
+    bool ok;
+    if (l.f64) ok = rbgs ? smooth_folded_t<double, 1>(s, l, mu, coarse, pre, post, &launches, &nb)
+                         : smooth_folded_t<double, 0>(s, l, mu, coarse, pre, post, &launches, &nb);
+    else ok = rbgs ? smooth_folded_t<float, 1>(s, l, mu, coarse, pre, post, &launches, &nb)
+                   : smooth_folded_t<float, 0>(s, l, mu, coarse, pre, post, &launches, &nb);
     if (!ok) return false;
     p.set(launches, mu);
     if (post == 2) s->norm_blocks_ready = nb;
@@ -1220,8 +1242,8 @@ long mgx_slab_scratch_doubles(const mgx_slab* s)
     return cap + 8;
 }
 
-int mgx_slab_jacobi(const mgx_slab* s, void* u, const void* b, void* tmp, int row_lo, int row_hi, int mu,
-                    double omega, int shrink, int* result_in_tmp, void* stream)
+static int slab_smooth(int smoother, const mgx_slab* s, void* u, const void* b, void* tmp, int row_lo, int row_hi,
+                       int mu, double omega, int shrink, int* result_in_tmp, void* stream)
 {
     if (slab_check(s) || !u || !b || !tmp || mu < 0) return MGX_ERR_INVALID;
     const int N = 1 << s->level;
@@ -1231,38 +1253,26 @@ int mgx_slab_jacobi(const mgx_slab* s, void* u, const void* b, void* tmp, int ro
     const FuseCfg fc = fuse_cfg();
     int parity = 0, rc;
     if (s->dtype == MGX_DTYPE_F64)
-        rc = jacobi_block<double>((double*)u, (const double*)b, (double*)tmp, N, pitch, s->rows, row_lo, row_hi, mu,
-                                  omega, shrink != 0, first, last, rpc, fc, (hipStream_t)stream, &parity);
+        rc = smooth_block<double>(smoother, (double*)u, (const double*)b, (double*)tmp, N, pitch, s->rows, row_lo, row_hi,
+                                  mu, omega, shrink != 0, first, last, s->row0 & 1, rpc, fc, (hipStream_t)stream, &parity);
     else
-        rc = jacobi_block<float>((float*)u, (const float*)b, (float*)tmp, N, pitch, s->rows, row_lo, row_hi, mu,
-                                 omega, shrink != 0, first, last, rpc, fc, (hipStream_t)stream, &parity);
+        rc = smooth_block<float>(smoother, (float*)u, (const float*)b, (float*)tmp, N, pitch, s->rows, row_lo, row_hi,
+                                 mu, omega, shrink != 0, first, last, s->row0 & 1, rpc, fc, (hipStream_t)stream, &parity);
     if (rc) return rc;
     if (result_in_tmp) *result_in_tmp = parity;
     return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_HIP;
 }
 
+int mgx_slab_jacobi(const mgx_slab* s, void* u, const void* b, void* tmp, int row_lo, int row_hi, int mu,
+                    double omega, int shrink, int* result_in_tmp, void* stream)
+{
+    return slab_smooth(MGX_SMOOTHER_JACOBI, s, u, b, tmp, row_lo, row_hi, mu, omega, shrink, result_in_tmp, stream);
+}
+
 int mgx_slab_rbgs(const mgx_slab* s, void* u, const void* b, void* tmp, int row_lo, int row_hi, int mu,
                   int shrink, int* result_in_tmp, void* stream)
 {
-    if (slab_check(s) || !u || !b || !tmp || mu < 0) return MGX_ERR_INVALID;
-    const int N = 1 << s->level;
-    const long pitch = level_pitch(s->level, s->dtype);
-    const int bnd_lo = -s->row0, bnd_hi = N - s->row0;
-    const int rpc = env_int("MGX_ROWS", 0);
-    void* src = u; void* dst = tmp;
-    for (int k = 0; k < mu; ++k) {
-        const int ext = shrink ? 2 * (mu - 1 - k) : 0;
-        const int lo = std::max(row_lo - ext, bnd_lo + 1), hi = std::min(row_hi + ext, bnd_hi);
-        // rows lo-2 .. hi+1 are read unless they lie beyond a global boundary row
-        if (std::max(lo - 2, bnd_lo) < 0 || std::min(hi + 1, bnd_hi) > s->rows - 1) return MGX_ERR_INVALID;
-        if (s->dtype == MGX_DTYPE_F64)
-            launch_rbgs<double>((const double*)src, (const double*)b, (double*)dst, N, pitch, lo, hi, s->row0 & 1, bnd_lo, bnd_hi, rpc, (hipStream_t)stream);
-        else
-            launch_rbgs<float>((const float*)src, (const float*)b, (float*)dst, N, pitch, lo, hi, s->row0 & 1, bnd_lo, bnd_hi, rpc, (hipStream_t)stream);
-        std::swap(src, dst);
-    }
-    if (result_in_tmp) *result_in_tmp = (mu & 1);
-    return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_HIP;
+    return slab_smooth(MGX_SMOOTHER_RBGS, s, u, b, tmp, row_lo, row_hi, mu, 1.0, shrink, result_in_tmp, stream);
 }
 
 int mgx_slab_restrict(const mgx_slab* f, const void* u, const void* b, const mgx_slab* c, void* cb, void* zero_u,

@@ -325,11 +325,27 @@ k_rbgs(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vou
 // bnd_lo / bnd_hi: local indices of the global boundary rows (slabs); rows
 // [max(row_lo-K, bnd_lo), min(row_hi+K-1, bnd_hi)] must exist.
 // =============================================================================
-template <typename T, int K>
+// One level of a fused pass.  SM = 0: a weighted-Jacobi sweep.  SM = 1: half a
+// red-black Gauss-Seidel sweep - odd levels update the red points (row + col
+// even), even levels the black ones, so s sweeps are 2 s levels; `par` is the
+// parity of (global row + first column of the vector).
+template <typename T, int SM>
+__device__ __forceinline__ typename VecOf<T>::type
+level_op(int j, const typename VecOf<T>::type& up, const typename VecOf<T>::type& cur,
+         const typename VecOf<T>::type& dn, const typename VecOf<T>::type& bb, T c0, T c1, int par)
+{
+    if constexpr (SM == 0) {
+        return jacobi_vec<T>(up, cur, dn, bb, c0, c1);
+    } else {
+        return ((j - 1) & 1) ? gs_colour<1>(up, cur, dn, bb, par) : gs_colour<0>(up, cur, dn, bb, par);
+    }
+}
+
+template <typename T, int K, int SM = 0>
 __global__ void __launch_bounds__(kBlock)
 k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
                int N, long pitch, int row_lo, int row_hi, int R, int strips, int chunks,
-               T c0, T c1, int bnd_lo, int bnd_hi)
+               T c0, T c1, int bnd_lo, int bnd_hi, int row_parity)
 {
     using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
@@ -368,7 +384,8 @@ k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         for (int j = 1; j <= K; ++j) {
             // level-j row (y - j) from level-(j-1) rows (y-j-1, y-j, y-j+1) and rhs row y-j
             const int row = y - j;
-            V o = jacobi_vec<T>(lev[j - 1][0], lev[j - 1][1], lev[j - 1][2], bw[j - 1], c0, c1);
+            V o = level_op<T, SM>(j, lev[j - 1][0], lev[j - 1][1], lev[j - 1][2], bw[j - 1], c0, c1,
+                                  row_parity + row + (int)(col & 1));
             mask_cols(o, col, N);
             if (!(row > bnd_lo && row < bnd_hi)) o = Z;          // Dirichlet rows stay zero
             if (j < K) {
@@ -646,7 +663,7 @@ k_prolong(T* __restrict__ v, const T* __restrict__ coarse, int N, long pitch, lo
 template <int K, int POST> constexpr int cycle_halo_cols() { return K + (POST == 1 ? 2 : (POST == 2 ? 1 : 0)); }
 template <int K, int POST, int W> constexpr int cycle_out_lanes() { return kWave - 2 * ((cycle_halo_cols<K, POST>() + W - 1) / W); }
 
-template <typename T, int K, int PRE, int POST>
+template <typename T, int K, int PRE, int POST, int SM = 0>
 __global__ void __launch_bounds__(kBlock)
 k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
                const T* __restrict__ coarse_e,                       // PRE
@@ -734,7 +751,8 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
 #pragma unroll
             for (int j = 1; j <= K; ++j) {
                 const int row = y - j;
-                V o = jacobi_vec<T>(lev[j - 1][0], lev[j - 1][1], lev[j - 1][2], bw[j - 1], c0, c1);
+                V o = level_op<T, SM>(j, lev[j - 1][0], lev[j - 1][1], lev[j - 1][2], bw[j - 1], c0, c1,
+                                      row + (int)(col & 1));
                 mask_cols(o, col, N);
                 if (!(row > bnd_lo && row < bnd_hi)) o = Z;
                 if (j == K) vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);

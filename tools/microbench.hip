@@ -234,12 +234,45 @@ void run_level(int level, int iters)
         g.blocks = (int)(((waves + 3) / 4 + 7) / 8 * 8);
         T* src = u; T* dst = tmp;
         float ms = tm.run([&] {
-            hipLaunchKernelGGL((k_jacobi_fused<T, K>), dim3(g.blocks), dim3(kBlock), 0, 0, src, b, dst, N, pitch, 1, N, g.R, g.strips, g.chunks, c0, c1, 0, N);
+            hipLaunchKernelGGL((k_jacobi_fused<T, K, 0>), dim3(g.blocks), dim3(kBlock), 0, 0, src, b, dst, N, pitch, 1, N, g.R, g.strips, g.chunks, c0, c1, 0, N, 0);
             std::swap(src, dst);
         }, 3, iters);
         char nm[64]; snprintf(nm, sizeof nm, "jacobi fused K=%d R=%d (per sweep)", K, R);
         report(nm, ms / K, 3.0 * sizeof(T));
     };
+    auto fused_gs = [&](auto kc, int R) {
+        constexpr int K = decltype(kc)::value;       // levels = 2 x sweeps
+        constexpr int OUT = fused_out_lanes<K, W>();
+        Launch g = make_launch(N, W, N - 1, R);
+        g.strips = (N / W + OUT - 1) / OUT;
+        const long waves = (long)g.strips * g.chunks;
+        g.blocks = (int)(((waves + 3) / 4 + 7) / 8 * 8);
+        T* src = u; T* dst = tmp;
+        float ms = tm.run([&] {
+            hipLaunchKernelGGL((k_jacobi_fused<T, K, 1>), dim3(g.blocks), dim3(kBlock), 0, 0, src, b, dst, N, pitch, 1, N, g.R, g.strips, g.chunks, c0, c1, 0, N, 0);
+            std::swap(src, dst);
+        }, 3, iters);
+        char nm[64]; snprintf(nm, sizeof nm, "rbgs fused sweeps=%d R=%d (per sweep)", K / 2, R);
+        report(nm, ms / (K / 2), 3.0 * sizeof(T));
+    };
+    for (int R : {8, 16, 32, 64, 128}) {
+        if (R * 4 > N) continue;
+        fused_gs(std::integral_constant<int, 2>{}, R);
+        fused_gs(std::integral_constant<int, 4>{}, R);
+        fused_gs(std::integral_constant<int, 6>{}, R);
+        fused_gs(std::integral_constant<int, 8>{}, R);
+        fused_gs(std::integral_constant<int, 10>{}, R);
+    }
+    for (int R : {8, 16, 32}) {
+        const Launch g = make_launch(N, W, N - 1, R);
+        T* src = u; T* dst = tmp;
+        float ms = tm.run([&] {
+            hipLaunchKernelGGL((k_rbgs<T>), dim3(g.blocks), dim3(kBlock), 0, 0, src, b, dst, N, pitch, 1, N, g.R, g.strips, g.chunks, 0, 0, N);
+            std::swap(src, dst);
+        }, 3, iters);
+        char nm[64]; snprintf(nm, sizeof nm, "rbgs one-pass k_rbgs R=%d", R);
+        report(nm, ms, 3.0 * sizeof(T));
+    }
     for (int R : {8, 16, 32, 64, 128}) {
         if (R * 4 > N) continue;
         fused(std::integral_constant<int, 2>{}, R);
