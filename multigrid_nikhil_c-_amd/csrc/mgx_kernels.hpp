@@ -61,10 +61,25 @@ __device__ __forceinline__ double last(const double2& v)  { return v.y; }
 __device__ __forceinline__ float  first(const float4& v)  { return v.x; }
 __device__ __forceinline__ float  last(const float4& v)   { return v.w; }
 
-// value held by the lane one to the left / right (wave64 shuffles).  Lane 0's
-// "left" and lane 63's "right" are don't-cares: those lanes never store.
-template <typename T> __device__ __forceinline__ T from_left(T x)  { return __shfl_up(x, 1, kWave); }
-template <typename T> __device__ __forceinline__ T from_right(T x) { return __shfl_down(x, 1, kWave); }
+// value held by the lane one to the left / right: DPP wavefront shifts
+// (v_mov_b32_dpp wave_shr:1 / wave_shl:1), i.e. plain VALU moves with no LDS
+// round trip - __shfl_up/down lower to ds_bpermute_b32, whose latency sits in
+// the serial level-to-level dependency chain of the fused kernels.  Semantics
+// checked on MI355X: identical to __shfl_up/down(x, 1, 64), edge lanes keep
+// their own value (lane 0's "left" and lane 63's "right" are don't-cares:
+// halo lanes never store).
+__device__ __forceinline__ int dpp_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_shl1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ float from_left(float x)  { return __int_as_float(dpp_shr1(__float_as_int(x))); }
+__device__ __forceinline__ float from_right(float x) { return __int_as_float(dpp_shl1(__float_as_int(x))); }
+__device__ __forceinline__ double from_left(double x)
+{
+    return __hiloint2double(dpp_shr1(__double2hiint(x)), dpp_shr1(__double2loint(x)));
+}
+__device__ __forceinline__ double from_right(double x)
+{
+    return __hiloint2double(dpp_shl1(__double2hiint(x)), dpp_shl1(__double2loint(x)));
+}
 
 // ---- wave -> (row chunk, column strip) --------------------------------------
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an XCD and its
