@@ -170,7 +170,7 @@ void launch_rbgs(const T* vin, const T* b, T* vout, int N, long pitch, int row_l
 // red-black Gauss-Seidel sweeps (SM = 1)
 template <typename T, int K, int SM>
 void launch_fused_k(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
-                    T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st)
+                    T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st, int rows_alloc)
 {
     constexpr int OUT = fused_out_lanes<K, VecOf<T>::W>();
     Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, R);
@@ -178,25 +178,26 @@ void launch_fused_k(const T* vin, const T* b, T* vout, int N, long pitch, int ro
     const long waves = (long)g.strips * g.chunks;
     g.blocks = (int)(((waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
     hipLaunchKernelGGL((k_jacobi_fused<T, K, SM>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
-                       row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, bnd_lo, bnd_hi, row_parity);
+                       row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, bnd_lo, bnd_hi, row_parity, rows_alloc);
 }
 
+// rows_alloc: number of rows the arrays hold (every load is bounded by it)
 template <typename T, int SM>
 bool launch_fused(int K, const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
-                  T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st)
+                  T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st, int rows_alloc)
 {
     switch (K) {
-        case 2: launch_fused_k<T, 2, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
-        case 4: launch_fused_k<T, 4, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
-        case 6: launch_fused_k<T, 6, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
-        case 8: launch_fused_k<T, 8, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
-        case 10: launch_fused_k<T, 10, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
+        case 2: launch_fused_k<T, 2, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
+        case 4: launch_fused_k<T, 4, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
+        case 6: launch_fused_k<T, 6, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
+        case 8: launch_fused_k<T, 8, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
+        case 10: launch_fused_k<T, 10, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
         default: break;
     }
     if constexpr (SM == 0) {
         switch (K) {
-            case 3: launch_fused_k<T, 3, 0>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
-            case 5: launch_fused_k<T, 5, 0>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st); return true;
+            case 3: launch_fused_k<T, 3, 0>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
+            case 5: launch_fused_k<T, 5, 0>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
             default: break;
         }
     }
@@ -208,7 +209,7 @@ bool launch_fused(int K, const T* vin, const T* b, T* vout, int N, long pitch, i
 inline int fuse_rows(const FuseCfg& fc, int N, int K)
 {
     if (fc.rows > 0) return fc.rows;
-    if (K <= 3) return 8;
+    if (K <= 4) return 8;
     int R = N / 128;
     if (R < 8) R = 8;
     if (R > 64) R = 64;
@@ -230,11 +231,11 @@ inline FuseCfg fuse_cfg()
 // measured on MI355X at 8192^2 (tools/microbench, profiles/r01_fused_microbench.md).
 // Index = sweeps per launch; 0 = not instantiated.  Jacobi: K = 5 is poor in
 // float because it needs a second halo lane per side for one extra column.
-constexpr double kFuseRate64[11] = {0, 1.00, 1.72, 2.52, 3.37, 4.11, 4.45, 0, 4.15, 0, 3.78};
-constexpr double kFuseRate32[11] = {0, 1.00, 1.65, 2.42, 3.13, 2.66, 3.60, 0, 3.89, 0, 3.24};
+constexpr double kFuseRate64[11] = {0, 1.00, 1.80, 2.45, 3.16, 3.81, 4.72, 0, 4.98, 0, 5.55};
+constexpr double kFuseRate32[11] = {0, 1.00, 1.66, 2.29, 2.72, 3.19, 3.07, 0, 4.00, 0, 2.99};
 // red-black Gauss-Seidel: s sweeps = 2 s levels, s <= 5
-constexpr double kFuseRateGS64[11] = {0, 1.00, 1.83, 2.45, 2.50, 2.12, 0, 0, 0, 0, 0};
-constexpr double kFuseRateGS32[11] = {0, 1.00, 1.81, 2.10, 2.45, 1.86, 0, 0, 0, 0, 0};
+constexpr double kFuseRateGS64[11] = {0, 1.00, 1.81, 2.50, 3.19, 3.12, 0, 0, 0, 0, 0};
+constexpr double kFuseRateGS32[11] = {0, 1.00, 1.79, 2.20, 2.87, 2.69, 0, 0, 0, 0, 0};
 
 // split mu sweeps into fused launches minimising the modelled time; parts[] gets
 // the sweeps of each launch, returns their count.  kmax bounds the LEVELS per pass.
@@ -297,8 +298,8 @@ int smooth_block(int smoother, T* a, const T* rhs, T* b2, int N, long pitch, int
                 launch_rbgs<T>(src, rhs, dst, N, pitch, lo, hi, row_parity, bl, bh, rpc, st);
             } else {
                 const int R = fuse_rows(fc, N, K);
-                const bool ok = rbgs ? launch_fused<T, 1>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st)
-                                     : launch_fused<T, 0>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st);
+                const bool ok = rbgs ? launch_fused<T, 1>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st, rows_alloc)
+                                     : launch_fused<T, 0>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st, rows_alloc);
                 if (!ok) return MGX_ERR_INVALID;
             }
         }
@@ -347,6 +348,7 @@ int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, i
         case 4: return launch_cycle_k<T, 4, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
         case 6: return launch_cycle_k<T, 6, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
         case 8: return launch_cycle_k<T, 8, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        case 10: return launch_cycle_k<T, 10, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
         default: break;
     }
     if constexpr (SM == 0) {
@@ -361,7 +363,10 @@ int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, i
 }
 
 // levels per pass the folded kernels are instantiated for
-inline bool cycle_k_supported(int K, bool rbgs) { return rbgs ? (K == 2 || K == 4 || K == 6 || K == 8) : (K >= 1 && K <= 8 && K != 7); }
+inline bool cycle_k_supported(int K, bool rbgs)
+{
+    return rbgs ? (K == 2 || K == 4 || K == 6 || K == 8 || K == 10) : ((K >= 1 && K <= 8 && K != 7) || K == 10);
+}
 
 template <typename T>
 void launch_restrict(const T* v, const T* b, T* cb, T* czero, int N, long pitch, long cpitch,
@@ -531,6 +536,16 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
 // (post = 1) or the residual norm (post = 2) produced by the last pass.
 // Returns false when this level / configuration is not eligible (caller then
 // uses the stand-alone kernels); on success *norm_blocks = partial sums written.
+// Levels per pass for the folded kernels.  They carry one more level window and the
+// transfer state, so their sweet spot is shallower than the plain fused kernel's:
+// measured on one MI355X in one process, V(10,10) at 8192^2 fp64 takes 2.67 ms as
+// [5,5], 2.84 as [6,4] and 2.82 as [10] (244-256 VGPRs, 2 waves/SIMD).
+inline int fold_kmax(const mgx_solver* s)
+{
+    static const int env = env_int("MGX_FOLD_KMAX", 5);
+    return std::max(1, std::min(s->fuse.kmax, env));
+}
+
 template <typename T, int SM>
 bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool pre, int post, int* launches,
                      int* norm_blocks)
@@ -538,7 +553,7 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
     constexpr bool rbgs = (SM == 1);
     constexpr int per = rbgs ? 2 : 1;
     int parts[64];
-    const int np = plan_fusion(mu, std::min(s->fuse.kmax, 8), sizeof(T) == 8, parts, rbgs);
+    const int np = plan_fusion(mu, fold_kmax(s), sizeof(T) == 8, parts, rbgs);
     const T om = (T)s->cfg.omega;
     const T c0 = (T)(1.0 - (double)om);
     const T c1 = (T)((double)om / 4.0);
@@ -560,7 +575,7 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
         else if (Q == 1) blocks = launch_cycle<T, 0, 1, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
         else if (Q == 2) blocks = launch_cycle<T, 0, 2, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
         else if (!rbgs && K == 1) launch_jacobi<T>(src, b, dst, l.N, l.pitch, 1, l.N, s->cfg.omega, s->rows_per_chunk, s->stream);
-        else (void)launch_fused<T, SM>(K, src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, 0, R, s->stream);
+        else (void)launch_fused<T, SM>(K, src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, 0, R, s->stream, l.rows);
         if (Q == 2) *norm_blocks = blocks;
         std::swap(src, dst);
     }
@@ -577,7 +592,7 @@ bool fold_eligible(const mgx_solver* s, const Level& l, int mu)
     const int per = rbgs ? 2 : 1;
     if (s->fuse.kmax < per) return false;
     int parts[64];
-    const int np = plan_fusion(mu, std::min(s->fuse.kmax, 8), l.f64, parts, rbgs);
+    const int np = plan_fusion(mu, fold_kmax(s), l.f64, parts, rbgs);
     for (int p = 0; p < np; ++p)
         if (!cycle_k_supported(per * parts[p], rbgs)) return false;
     // the norm partials of the folded pass must fit the reduction buffer

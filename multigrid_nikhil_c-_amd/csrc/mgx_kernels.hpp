@@ -356,13 +356,84 @@ level_op(int j, const typename VecOf<T>::type& up, const typename VecOf<T>::type
     }
 }
 
+// EDGE = false: the wave's whole dependency cone lies strictly inside the grid
+// (no Dirichlet row or column, no padding): every predicate, mask and select of
+// the general body is statically true/absent.  Most waves take this path.
+//
+// One row step at rotation phase P.  Each level keeps its 3-row window in three
+// fixed register slots; the incoming row overwrites the slot of the row that
+// just died, so (oldest, middle, newest) = slots ((P+1)%3, (P+2)%3, P) and no
+// window is ever shifted by register moves (the loop below runs P = 0,1,2).
+template <typename T, int K, int SM, bool EDGE, int P>
+__device__ __forceinline__ void
+fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K], int y,
+           const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po, long pitch, long col, int N,
+           int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int par_c)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int S_OLD = (P + 1) % 3, S_MID = (P + 2) % 3, S_NEW = P;
+    const V Z = vzero((V*)nullptr);
+    // level 0: input row y; rhs row y-1 (consumed by the level-1 update of row y-1)
+    V in, bn;
+    if (EDGE) {
+        // [rd_lo, rd_hi]: rows inside the allocation and not beyond a boundary row
+        in = vload<V>(pv + (long)y * pitch, ld && y >= rd_lo && y <= rd_hi && y < r1 + K);
+        // rhs rows are needed only where some level is: [r0-K+1, r1+K-1)
+        bn = vload<V>(pb + (long)(y - 1) * pitch,
+                      ld && (y - 1) > bnd_lo && (y - 1) < bnd_hi && (y - 1) >= rd_lo && (y - 1) <= rd_hi &&
+                      y >= r0 - K + 2 && y < r1 + K);
+    } else {
+        in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
+        bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
+    }
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) bw[j] = bw[j - 1];
+    bw[0] = bn;
+    lev[0][S_NEW] = in;
+#pragma unroll
+    for (int j = 1; j <= K; ++j) {
+        // level-j row (y - j) from level-(j-1) rows (y-j-1, y-j, y-j+1) and rhs row y-j
+        const int row = y - j;
+        V o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1, par_c + row);
+        if (EDGE) {
+            mask_cols(o, col, N);
+            if (!(row > bnd_lo && row < bnd_hi)) o = Z;          // Dirichlet rows stay zero
+        }
+        if (j < K) lev[j][S_NEW] = o;
+        else vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);
+    }
+}
+
+template <typename T, int K, int SM, bool EDGE>
+__device__ __forceinline__ void
+fused_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po, long pitch, long col, int N,
+           int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int row_parity)
+{
+    using V = typename VecOf<T>::type;
+    const V Z = vzero((V*)nullptr);
+    V lev[K][3];          // lev[j] = the three most recent level-j rows, rotating slots
+    V bw[K];              // bw[j]  = rhs row y-1-j
+#pragma unroll
+    for (int j = 0; j < K; ++j) { lev[j][0] = Z; lev[j][1] = Z; lev[j][2] = Z; bw[j] = Z; }
+    const int par_c = row_parity + (int)(col & 1);
+    // steps y = r0-K .. r1+K-1, rounded up to a multiple of 3 (the extra steps
+    // store nothing; in the EDGE body their loads are predicated, in the
+    // interior body the caller guarantees two more rows exist below the cone)
+    const int y0 = r0 - K;
+    const int steps = (r1 + K - y0 + 2) / 3 * 3;
+    for (int y = y0; y < y0 + steps; y += 3) {
+        fused_step<T, K, SM, EDGE, 0>(lev, bw, y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c);
+        fused_step<T, K, SM, EDGE, 1>(lev, bw, y + 1, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c);
+        fused_step<T, K, SM, EDGE, 2>(lev, bw, y + 2, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c);
+    }
+}
+
 template <typename T, int K, int SM = 0>
 __global__ void __launch_bounds__(kBlock)
 k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
                int N, long pitch, int row_lo, int row_hi, int R, int strips, int chunks,
-               T c0, T c1, int bnd_lo, int bnd_hi, int row_parity)
+               T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int rows_alloc)
 {
-    using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
     constexpr int HL = (K + W - 1) / W;           // halo lanes per side
     constexpr int OUT = kWave - 2 * HL;           // storing lanes per wave
@@ -378,38 +449,18 @@ k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     const T* pv = vin + col;
     const T* pb = rhs + col;
     T* po = vout + col;
-    const V Z = vzero((V*)nullptr);
-
-    V lev[K][3];          // lev[j] = level-j rows (y-j-2, y-j-1, y-j)
-    V bw[K];              // bw[j]  = rhs row y-1-j
-#pragma unroll
-    for (int j = 0; j < K; ++j) { lev[j][0] = Z; lev[j][1] = Z; lev[j][2] = Z; bw[j] = Z; }
-
-    for (int y = r0 - K; y < r1 + K; ++y) {
-        // level 0: input row y; rhs row y-1 (consumed by the level-1 update of row y-1)
-        const V in = vload<V>(pv + (long)y * pitch, ld && y >= bnd_lo && y <= bnd_hi);
-        // rhs rows are needed only where some level is: [r0-K+1, r1+K-1)
-        const V bn = vload<V>(pb + (long)(y - 1) * pitch,
-                              ld && (y - 1) > bnd_lo && (y - 1) < bnd_hi && y >= r0 - K + 2 && y < r1 + K);
-#pragma unroll
-        for (int j = K - 1; j > 0; --j) bw[j] = bw[j - 1];
-        bw[0] = bn;
-        lev[0][0] = lev[0][1]; lev[0][1] = lev[0][2]; lev[0][2] = in;
-#pragma unroll
-        for (int j = 1; j <= K; ++j) {
-            // level-j row (y - j) from level-(j-1) rows (y-j-1, y-j, y-j+1) and rhs row y-j
-            const int row = y - j;
-            V o = level_op<T, SM>(j, lev[j - 1][0], lev[j - 1][1], lev[j - 1][2], bw[j - 1], c0, c1,
-                                  row_parity + row + (int)(col & 1));
-            mask_cols(o, col, N);
-            if (!(row > bnd_lo && row < bnd_hi)) o = Z;          // Dirichlet rows stay zero
-            if (j < K) {
-                lev[j][0] = lev[j][1]; lev[j][1] = lev[j][2]; lev[j][2] = o;
-            } else {
-                vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);
-            }
-        }
-    }
+    // Rows that may be dereferenced at all: inside the allocation AND not beyond a
+    // global boundary row (on a slab the allocation ends long before the boundary).
+    const int rd_lo = max(bnd_lo, 0), rd_hi = min(bnd_hi, rows_alloc - 1);
+    // wave-uniform: does everything the unpredicated body touches - rows r0-K-1 .. r1+K+1
+    // (the step count is rounded up to a multiple of 3), vectors one beyond the first and
+    // last lane - lie strictly inside the unknowns and inside the allocation?
+    const int vx0 = t.strip * OUT - HL;
+    const bool interior = (vx0 >= 1) && ((long)(vx0 + kWave) * W < N) &&
+                          (r0 - K - 1 > bnd_lo) && (r0 - K - 1 >= 0) &&
+                          (r1 + K + 2 < bnd_hi) && (r1 + K + 2 <= rows_alloc - 1);
+    if (interior) fused_body<T, K, SM, false>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity);
+    else fused_body<T, K, SM, true>(pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity);
 }
 
 template <int K, int W> constexpr int fused_out_lanes() { return kWave - 2 * ((K + W - 1) / W); }
@@ -678,6 +729,185 @@ k_prolong(T* __restrict__ v, const T* __restrict__ coarse, int N, long pitch, lo
 template <int K, int POST> constexpr int cycle_halo_cols() { return K + (POST == 1 ? 2 : (POST == 2 ? 1 : 0)); }
 template <int K, int POST, int W> constexpr int cycle_out_lanes() { return kWave - 2 * ((cycle_halo_cols<K, POST>() + W - 1) / W); }
 
+// per-wave state of a folded pass that is not a level window
+// (plain scalars, assigned member by member: aggregate copies of a 24-byte
+// Trip<double> were lowered to scratch memcpys)
+template <typename T, int CW> struct CycleState {
+    // POST 1: left / centre / right residuals of rows 2I-1 (t*) and 2I (m*) of the
+    // coarse row being assembled, per coarse column of the lane
+    T tl[CW], tc[CW], tr[CW], ml[CW], mc[CW], mr[CW];
+    double acc;                 // POST 2: sum of r^2
+};
+
+struct CycleArgs {              // what the stages besides the smoother need (uniform)
+    long cpitch; int NC;
+    int r0, r1, y_end;
+};
+
+// one row step of k_jacobi_cycle at window-rotation phase P (see fused_step)
+template <typename T, int K, int PRE, int POST, int SM, bool EDGE, int P>
+__device__ __forceinline__ void
+cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&bw)[K + 1],
+           CycleState<T, VecOf<T>::W / 2>& cs, int y,
+           const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
+           const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
+           long pitch, long col, long ccol, int N, const CycleArgs& ca, bool ld, bool cld, bool st, T c0, T c1)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int W = VecOf<T>::W;
+    constexpr int CW = W / 2;
+    constexpr int S_OLD = (P + 1) % 3, S_MID = (P + 2) % 3, S_NEW = P;
+    constexpr int bnd_lo = 0;
+    const int bnd_hi = N;
+    const V Z = vzero((V*)nullptr);
+    const int r0 = ca.r0, r1 = ca.r1;
+
+    V in, bn;
+    if (EDGE) {
+        in = vload<V>(pv + (long)y * pitch, ld && y >= bnd_lo && y <= bnd_hi && y < ca.y_end);
+        bn = vload<V>(pb + (long)(y - 1) * pitch, ld && (y - 1) > bnd_lo && (y - 1) < bnd_hi && y <= ca.y_end);
+    } else {
+        in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
+        bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
+    }
+    if (PRE) {
+        // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624)
+        const int I = y >> 1;
+        T a[CW + 1], b2[CW + 1], o[W];
+        const bool cl = EDGE ? (cld && y > bnd_lo && y < bnd_hi) : true;
+        {
+            const T* p = coarse_e + (long)I * ca.cpitch + ccol;
+#pragma unroll
+            for (int k = 0; k <= CW; ++k) a[k] = cl ? p[k] : (T)0;
+        }
+        if ((y & 1) == 0) {
+#pragma unroll
+            for (int k = 0; k < CW; ++k) { o[2 * k] = a[k]; o[2 * k + 1] = (T)0.5 * (a[k] + a[k + 1]); }
+        } else {
+            const T* p = coarse_e + (long)(I + 1) * ca.cpitch + ccol;
+#pragma unroll
+            for (int k = 0; k <= CW; ++k) b2[k] = cl ? p[k] : (T)0;
+#pragma unroll
+            for (int k = 0; k < CW; ++k) {
+                o[2 * k] = (T)0.5 * (a[k] + b2[k]);
+                o[2 * k + 1] = (T)0.25 * (((a[k] + b2[k]) + a[k + 1]) + b2[k + 1]);
+            }
+        }
+        V add;
+        if constexpr (W == 2) add = make_double2(o[0], o[1]);
+        else add = make_float4(o[0], o[1], o[2], o[3]);
+        if (EDGE) mask_cols(add, col, N);
+        if constexpr (W == 2) { in.x = in.x + add.x; in.y = in.y + add.y; }
+        else { in.x = in.x + add.x; in.y = in.y + add.y; in.z = in.z + add.z; in.w = in.w + add.w; }
+    }
+#pragma unroll
+    for (int j = K; j > 0; --j) bw[j] = bw[j - 1];
+    bw[0] = bn;
+    lev[0][S_NEW] = in;
+#pragma unroll
+    for (int j = 1; j <= K; ++j) {
+        const int row = y - j;
+        V o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1,
+                              row + (int)(col & 1));
+        if (EDGE) {
+            mask_cols(o, col, N);
+            if (!(row > bnd_lo && row < bnd_hi)) o = Z;
+        }
+        if (j == K) vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);
+        if (j < K || POST) lev[j][S_NEW] = o;
+    }
+    if (POST) {
+        // residual of the new iterate on row rho = y-K-1 (rows rho-1, rho, rho+1 of level K)
+        const int rho = y - K - 1;
+        V res = residual_vec(lev[K][S_OLD], lev[K][S_MID], lev[K][S_NEW], bw[K]);
+        if (EDGE) {
+            mask_cols(res, col, N);
+            if (!(rho > bnd_lo && rho < bnd_hi)) res = Z;
+        }
+        if (POST == 2) {
+            if (st && rho >= r0 && rho < r1) {
+                if constexpr (W == 2) cs.acc += (double)res.x * (double)res.x + (double)res.y * (double)res.y;
+                else cs.acc += ((double)res.x * (double)res.x + (double)res.y * (double)res.y) +
+                               ((double)res.z * (double)res.z + (double)res.w * (double)res.w);
+            }
+        } else {
+            T cl[CW], cc[CW], cr[CW];          // this row's residual left / centre / right per coarse column
+            const T l = from_left(last(res));
+            if constexpr (W == 2) { cl[0] = l; cc[0] = res.x; cr[0] = res.y; }
+            else { cl[0] = l; cc[0] = res.x; cr[0] = res.y; cl[1] = res.y; cc[1] = res.z; cr[1] = res.w; }
+            // rho odd (= 2I+1) closes coarse row I (top = 2I-1, mid = 2I, bot = this row) and
+            // becomes the next top; rho even becomes mid.  Written with selects, not
+            // branches: a branch on the run-time parity made the compiler index the
+            // state as a stack array (scratch).
+            const bool odd = (rho & 1) != 0;
+            const int I = (rho - 1) >> 1;
+            const bool emit = odd && (2 * I >= r0) && (2 * I < r1) && I >= 1 && I < ca.NC;
+            T o[CW];
+#pragma unroll
+            for (int k = 0; k < CW; ++k) {
+                // PS:539-542 order: ((nw+ne)+sw)+se + 2*(((w+e)+n)+s) + 4*c
+                T corners = cs.tl[k] + cs.tr[k]; corners = corners + cl[k]; corners = corners + cr[k];
+                T edges = cs.ml[k] + cs.mr[k]; edges = edges + cs.tc[k]; edges = edges + cc[k];
+                o[k] = wgt * ((corners + (T)2 * edges) + (T)4 * cs.mc[k]);
+                if (EDGE && (ccol + k == 0 || ccol + k >= ca.NC)) o[k] = (T)0;
+            }
+            if (st && emit) {
+                T* pc = coarse_b + (long)I * ca.cpitch + ccol;
+                if constexpr (CW == 1) { pc[0] = o[0]; }
+                else { *reinterpret_cast<float2*>(pc) = make_float2((float)o[0], (float)o[1]); }
+                if (coarse_zero) {
+                    T* pz = coarse_zero + (long)I * ca.cpitch + ccol;
+                    if constexpr (CW == 1) { pz[0] = (T)0; }
+                    else { *reinterpret_cast<float2*>(pz) = make_float2(0.f, 0.f); }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CW; ++k) {
+                cs.tl[k] = odd ? cl[k] : cs.tl[k]; cs.tc[k] = odd ? cc[k] : cs.tc[k]; cs.tr[k] = odd ? cr[k] : cs.tr[k];
+                cs.ml[k] = odd ? cs.ml[k] : cl[k]; cs.mc[k] = odd ? cs.mc[k] : cc[k]; cs.mr[k] = odd ? cs.mr[k] : cr[k];
+            }
+        }
+    }
+}
+
+template <typename T, int K, int PRE, int POST, int SM, bool EDGE>
+__device__ __forceinline__ double
+cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
+           const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
+           long pitch, long cpitch, long col, int N, int r0, int r1, bool ld, bool st, T c0, T c1)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int W = VecOf<T>::W;
+    constexpr int CW = W / 2;
+    constexpr int ETOP = POST ? 1 : 0;
+    constexpr int EBOT = POST == 1 ? 2 : (POST == 2 ? 1 : 0);
+    const V Z = vzero((V*)nullptr);
+    const long ccol = col / 2;
+    const bool cld = ld && (ccol + CW < cpitch);
+    V lev[K + 1][3];      // level windows in rotating slots; level K only when POST
+    V bw[K + 1];          // bw[j] = rhs row y-1-j
+#pragma unroll
+    for (int j = 0; j <= K; ++j) { lev[j][0] = Z; lev[j][1] = Z; lev[j][2] = Z; bw[j] = Z; }
+    CycleState<T, CW> cs;
+    cs.acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < CW; ++k) {
+        cs.tl[k] = cs.tc[k] = cs.tr[k] = (T)0;
+        cs.ml[k] = cs.mc[k] = cs.mr[k] = (T)0;
+    }
+    CycleArgs ca;
+    ca.cpitch = cpitch; ca.NC = N / 2; ca.r0 = r0; ca.r1 = r1;
+    const int y0 = r0 - K - ETOP;
+    ca.y_end = r1 + K + EBOT;                       // exclusive end of the steps that matter
+    const int steps = (ca.y_end - y0 + 2) / 3 * 3;  // rounded up to whole rotations
+    for (int y = y0; y < y0 + steps; y += 3) {
+        cycle_step<T, K, PRE, POST, SM, EDGE, 0>(lev, bw, cs, y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
+        cycle_step<T, K, PRE, POST, SM, EDGE, 1>(lev, bw, cs, y + 1, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
+        cycle_step<T, K, PRE, POST, SM, EDGE, 2>(lev, bw, cs, y + 2, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
+    }
+    return cs.acc;
+}
+
 template <typename T, int K, int PRE, int POST, int SM = 0>
 __global__ void __launch_bounds__(kBlock)
 k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
@@ -686,9 +916,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
                double* __restrict__ partial,                          // POST == 2
                int N, long pitch, long cpitch, int row_lo, int row_hi, int R, int strips, int chunks, T c0, T c1)
 {
-    using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
-    constexpr int CW = W / 2;
     constexpr int XC = cycle_halo_cols<K, POST>();
     constexpr int HL = (XC + W - 1) / W;
     constexpr int OUT = kWave - 2 * HL;
@@ -696,131 +924,26 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     constexpr int EBOT = POST == 1 ? 2 : (POST == 2 ? 1 : 0);
     __shared__ double wsum[kWavesPerBlock];
     const Tile t = wave_tile(strips, chunks);
-    const int bnd_lo = 0, bnd_hi = N;
     double acc = 0.0;
     if (t.active) {
         const int lane = threadIdx.x & 63;
-        const int vx = t.strip * OUT - HL + lane;
+        const int vx0 = t.strip * OUT - HL;
+        const int vx = vx0 + lane;
         const long col = (long)vx * W;
         const bool ld = (vx >= 0) && (col + W <= pitch);
         const bool st = (lane >= HL) && (lane < kWave - HL) && (vx < N / W);
         const int r0 = row_lo + t.chunk * R;
         const int r1 = min(r0 + R, row_hi);
-        const T* pv = vin + col;
-        const T* pb = rhs + col;
-        T* po = vout + col;
-        const V Z = vzero((V*)nullptr);
-        const long ccol = col / 2;
-        const int NC = N / 2;
-        const bool cld = ld && (ccol + CW < cpitch);
-
-        V lev[K + 1][3];      // lev[j] = level-j rows (y-j-2, y-j-1, y-j); level K only when POST
-        V bw[K + 1];          // bw[j]  = rhs row y-1-j
-#pragma unroll
-        for (int j = 0; j <= K; ++j) { lev[j][0] = Z; lev[j][1] = Z; lev[j][2] = Z; bw[j] = Z; }
-        Trip<T> top[CW], mid[CW];
-#pragma unroll
-        for (int k = 0; k < CW; ++k) { top[k] = {(T)0, (T)0, (T)0}; mid[k] = {(T)0, (T)0, (T)0}; }
-
-        const int y_first = r0 - K - ETOP;
-        const int y_end = r1 + K + EBOT;            // exclusive
-        for (int y = y_first; y < y_end; ++y) {
-            const bool unk = (y > bnd_lo && y < bnd_hi);
-            V in = vload<V>(pv + (long)y * pitch, ld && y >= bnd_lo && y <= bnd_hi);
-            if (PRE) {
-                // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624)
-                const int I = y >> 1;
-                T a[CW + 1], b2[CW + 1], o[W];
-                const bool cl = cld && unk;
-                {
-                    const T* p = coarse_e + (long)I * cpitch + ccol;
-#pragma unroll
-                    for (int k = 0; k <= CW; ++k) a[k] = cl ? p[k] : (T)0;
-                }
-                if ((y & 1) == 0) {
-#pragma unroll
-                    for (int k = 0; k < CW; ++k) { o[2 * k] = a[k]; o[2 * k + 1] = (T)0.5 * (a[k] + a[k + 1]); }
-                } else {
-                    const T* p = coarse_e + (long)(I + 1) * cpitch + ccol;
-#pragma unroll
-                    for (int k = 0; k <= CW; ++k) b2[k] = cl ? p[k] : (T)0;
-#pragma unroll
-                    for (int k = 0; k < CW; ++k) {
-                        o[2 * k] = (T)0.5 * (a[k] + b2[k]);
-                        o[2 * k + 1] = (T)0.25 * (((a[k] + b2[k]) + a[k + 1]) + b2[k + 1]);
-                    }
-                }
-                V add;
-                if constexpr (W == 2) add = make_double2(o[0], o[1]);
-                else add = make_float4(o[0], o[1], o[2], o[3]);
-                mask_cols(add, col, N);
-                if constexpr (W == 2) { in.x = in.x + add.x; in.y = in.y + add.y; }
-                else { in.x = in.x + add.x; in.y = in.y + add.y; in.z = in.z + add.z; in.w = in.w + add.w; }
-            }
-            const V bn = vload<V>(pb + (long)(y - 1) * pitch,
-                                  ld && (y - 1) > bnd_lo && (y - 1) < bnd_hi && y >= y_first + 1);
-#pragma unroll
-            for (int j = K; j > 0; --j) bw[j] = bw[j - 1];
-            bw[0] = bn;
-            lev[0][0] = lev[0][1]; lev[0][1] = lev[0][2]; lev[0][2] = in;
-#pragma unroll
-            for (int j = 1; j <= K; ++j) {
-                const int row = y - j;
-                V o = level_op<T, SM>(j, lev[j - 1][0], lev[j - 1][1], lev[j - 1][2], bw[j - 1], c0, c1,
-                                      row + (int)(col & 1));
-                mask_cols(o, col, N);
-                if (!(row > bnd_lo && row < bnd_hi)) o = Z;
-                if (j == K) vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);
-                if (j < K || POST) { lev[j][0] = lev[j][1]; lev[j][1] = lev[j][2]; lev[j][2] = o; }
-            }
-            if (POST) {
-                // residual of the new iterate on row rho = y-K-1 (rows rho-1, rho, rho+1 of level K)
-                const int rho = y - K - 1;
-                V res = residual_vec(lev[K][0], lev[K][1], lev[K][2], bw[K]);
-                mask_cols(res, col, N);
-                if (!(rho > bnd_lo && rho < bnd_hi)) res = Z;
-                if (POST == 2) {
-                    if (st && rho >= r0 && rho < r1) {
-                        if constexpr (W == 2) acc += (double)res.x * (double)res.x + (double)res.y * (double)res.y;
-                        else acc += ((double)res.x * (double)res.x + (double)res.y * (double)res.y) +
-                                    ((double)res.z * (double)res.z + (double)res.w * (double)res.w);
-                    }
-                } else {
-                    Trip<T> cur[CW];
-                    const T l = from_left(last(res));
-                    if constexpr (W == 2) { cur[0] = {l, res.x, res.y}; }
-                    else { cur[0] = {l, res.x, res.y}; cur[1] = {res.y, res.z, res.w}; }
-                    if (rho & 1) {
-                        // rho = 2I+1 closes coarse row I (top = 2I-1, mid = 2I, bot = cur)
-                        const int I = (rho - 1) >> 1;
-                        const bool emit = (2 * I >= r0) && (2 * I < r1) && I >= 1 && I < NC;
-                        T o[CW];
-#pragma unroll
-                        for (int k = 0; k < CW; ++k) {
-                            T corners = top[k].l + top[k].r; corners = corners + cur[k].l; corners = corners + cur[k].r;
-                            T edges = mid[k].l + mid[k].r; edges = edges + top[k].c; edges = edges + cur[k].c;
-                            o[k] = wgt * ((corners + (T)2 * edges) + (T)4 * mid[k].c);
-                            if (ccol + k == 0 || ccol + k >= NC) o[k] = (T)0;
-                        }
-                        if (st && emit) {
-                            T* pc = coarse_b + (long)I * cpitch + ccol;
-                            if constexpr (CW == 1) { pc[0] = o[0]; }
-                            else { *reinterpret_cast<float2*>(pc) = make_float2((float)o[0], (float)o[1]); }
-                            if (coarse_zero) {
-                                T* pz = coarse_zero + (long)I * cpitch + ccol;
-                                if constexpr (CW == 1) { pz[0] = (T)0; }
-                                else { *reinterpret_cast<float2*>(pz) = make_float2(0.f, 0.f); }
-                            }
-                        }
-#pragma unroll
-                        for (int k = 0; k < CW; ++k) top[k] = cur[k];
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < CW; ++k) mid[k] = cur[k];
-                    }
-                }
-            }
-        }
+        // everything the unpredicated body touches (rows r0-K-ETOP-1 .. r1+K+EBOT+1, one vector
+        // beyond the first and last lane, the matching coarse rows/columns) strictly inside
+        const bool interior = (vx0 >= 1) && ((long)(vx0 + kWave + 1) * W < N) &&
+                              (r0 - K - ETOP - 1 > 0) && (r1 + K + EBOT + 2 < N);
+        if (interior)
+            acc = cycle_body<T, K, PRE, POST, SM, false>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
+                                                         pitch, cpitch, col, N, r0, r1, true, st, c0, c1);
+        else
+            acc = cycle_body<T, K, PRE, POST, SM, true>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
+                                                        pitch, cpitch, col, N, r0, r1, ld, st, c0, c1);
     }
     if (POST == 2) {
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);

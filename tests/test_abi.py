@@ -87,3 +87,23 @@ def test_no_cpu_fallback(pkg):
     # slab operators validate their arguments before touching the device
     s = pkg.Slab(level=1, dtype=pkg.DTYPE_F64, rows=4, row0=0)
     assert pkg.lib().mgx_slab_scratch_doubles(C.byref(s)) == -1
+
+
+def test_no_kernel_uses_scratch(tmp_path):
+    """Register-resident row windows are the whole point of the fused kernels: a
+    spill (scratch) silently costs 30-60 %.  Cross-compile for gfx950 and check
+    every kernel's ScratchSize (this caught a run-time-indexed state array)."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "multigrid_nikhil_c-_amd", "csrc", "mgx.hip")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+                          "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "chk.so"), src],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    assert len(sizes) > 50, "resource-usage remarks missing"
+    assert max(sizes) == 0, f"{sum(1 for x in sizes if x)} kernels use scratch (max {max(sizes)} B/lane)"
