@@ -278,8 +278,8 @@ int smooth_block(int smoother, T* a, const T* rhs, T* b2, int N, long pitch, int
     int flips = 0;
     int done = 0;
     // Fused launches pay (R + 2K)/R redundant rows and need enough chunks to fill
-    // the chip: measured worthwhile from 1024^2 up, with R growing with the grid.
-    const bool allow_fuse = fc.kmax > per && N >= 1024 && (row_hi - row_lo) >= 64 && mu <= 64;
+    // the chip: measured worthwhile from 512^2 up, with R growing with the grid.
+    const bool allow_fuse = fc.kmax > per && N >= 512 && (row_hi - row_lo) >= 64 && mu <= 64;
     std::vector<int> parts(mu > 0 ? mu : 1, 1);
     const int nparts = allow_fuse ? plan_fusion(mu, fc.kmax, sizeof(T) == 8, parts.data(), rbgs) : mu;
     const int bl = first - 1, bh = last;
@@ -587,7 +587,7 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
 // pre-check made before any launch (so a `false` never leaves a half-done block)
 bool fold_eligible(const mgx_solver* s, const Level& l, int mu)
 {
-    if (!s->fold || mu < 1 || mu > 64 || l.N < 1024) return false;
+    if (!s->fold || mu < 1 || mu > 64 || l.N < 512) return false;
     const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
     const int per = rbgs ? 2 : 1;
     if (s->fuse.kmax < per) return false;

@@ -364,17 +364,14 @@ level_op(int j, const typename VecOf<T>::type& up, const typename VecOf<T>::type
 // fixed register slots; the incoming row overwrites the slot of the row that
 // just died, so (oldest, middle, newest) = slots ((P+1)%3, (P+2)%3, P) and no
 // window is ever shifted by register moves (the loop below runs P = 0,1,2).
-template <typename T, int K, int SM, bool EDGE, int P>
+// loads of one step: input row y and rhs row y-1
+template <typename T, int K, bool EDGE>
 __device__ __forceinline__ void
-fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K], int y,
-           const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po, long pitch, long col, int N,
-           int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int par_c)
+fused_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
+            const T* __restrict__ pv, const T* __restrict__ pb, long pitch, int r0, int r1, bool ld,
+            int bnd_lo, int bnd_hi, int rd_lo, int rd_hi)
 {
     using V = typename VecOf<T>::type;
-    constexpr int S_OLD = (P + 1) % 3, S_MID = (P + 2) % 3, S_NEW = P;
-    const V Z = vzero((V*)nullptr);
-    // level 0: input row y; rhs row y-1 (consumed by the level-1 update of row y-1)
-    V in, bn;
     if (EDGE) {
         // [rd_lo, rd_hi]: rows inside the allocation and not beyond a boundary row
         in = vload<V>(pv + (long)y * pitch, ld && y >= rd_lo && y <= rd_hi && y < r1 + K);
@@ -386,6 +383,23 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
         in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
         bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
     }
+}
+
+template <typename T, int K, int SM, bool EDGE, int P>
+__device__ __forceinline__ void
+fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K],
+           typename VecOf<T>::type& nin, typename VecOf<T>::type& nbn, int y,
+           const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po, long pitch, long col, int N,
+           int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int par_c)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int S_OLD = (P + 1) % 3, S_MID = (P + 2) % 3, S_NEW = P;
+    const V Z = vzero((V*)nullptr);
+    // level 0: input row y and rhs row y-1 were loaded during the previous step
+    // (software prefetch: on small grids there is ~1 wave per CU and nothing else
+    // hides the load latency); issue the next step's loads before computing
+    const V in = nin, bn = nbn;
+    fused_loads<T, K, EDGE>(nin, nbn, y + 1, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi);
 #pragma unroll
     for (int j = K - 1; j > 0; --j) bw[j] = bw[j - 1];
     bw[0] = bn;
@@ -418,13 +432,16 @@ fused_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     const int par_c = row_parity + (int)(col & 1);
     // steps y = r0-K .. r1+K-1, rounded up to a multiple of 3 (the extra steps
     // store nothing; in the EDGE body their loads are predicated, in the
-    // interior body the caller guarantees two more rows exist below the cone)
+    // interior body the caller guarantees three more rows exist below the cone:
+    // two for the rounding, one for the prefetch)
     const int y0 = r0 - K;
     const int steps = (r1 + K - y0 + 2) / 3 * 3;
+    V nin, nbn;
+    fused_loads<T, K, EDGE>(nin, nbn, y0, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi);
     for (int y = y0; y < y0 + steps; y += 3) {
-        fused_step<T, K, SM, EDGE, 0>(lev, bw, y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c);
-        fused_step<T, K, SM, EDGE, 1>(lev, bw, y + 1, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c);
-        fused_step<T, K, SM, EDGE, 2>(lev, bw, y + 2, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c);
+        fused_step<T, K, SM, EDGE, 0>(lev, bw, nin, nbn, y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c);
+        fused_step<T, K, SM, EDGE, 1>(lev, bw, nin, nbn, y + 1, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c);
+        fused_step<T, K, SM, EDGE, 2>(lev, bw, nin, nbn, y + 2, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c);
     }
 }
 
@@ -452,13 +469,13 @@ k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     // Rows that may be dereferenced at all: inside the allocation AND not beyond a
     // global boundary row (on a slab the allocation ends long before the boundary).
     const int rd_lo = max(bnd_lo, 0), rd_hi = min(bnd_hi, rows_alloc - 1);
-    // wave-uniform: does everything the unpredicated body touches - rows r0-K-1 .. r1+K+1
-    // (the step count is rounded up to a multiple of 3), vectors one beyond the first and
-    // last lane - lie strictly inside the unknowns and inside the allocation?
+    // wave-uniform: does everything the unpredicated body touches - rows r0-K-1 .. r1+K+2
+    // (the step count is rounded up to a multiple of 3, plus one prefetched row), vectors one
+    // beyond the first and last lane - lie strictly inside the unknowns and inside the allocation?
     const int vx0 = t.strip * OUT - HL;
     const bool interior = (vx0 >= 1) && ((long)(vx0 + kWave) * W < N) &&
                           (r0 - K - 1 > bnd_lo) && (r0 - K - 1 >= 0) &&
-                          (r1 + K + 2 < bnd_hi) && (r1 + K + 2 <= rows_alloc - 1);
+                          (r1 + K + 3 < bnd_hi) && (r1 + K + 3 <= rows_alloc - 1);
     if (interior) fused_body<T, K, SM, false>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity);
     else fused_body<T, K, SM, true>(pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity);
 }
@@ -745,9 +762,26 @@ struct CycleArgs {              // what the stages besides the smoother need (un
 };
 
 // one row step of k_jacobi_cycle at window-rotation phase P (see fused_step)
+// loads of one step of k_jacobi_cycle (whole grids: rows 0..N exist)
+template <typename T, bool EDGE>
+__device__ __forceinline__ void
+cycle_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
+            const T* __restrict__ pv, const T* __restrict__ pb, long pitch, int N, int y_end, bool ld)
+{
+    using V = typename VecOf<T>::type;
+    if (EDGE) {
+        in = vload<V>(pv + (long)y * pitch, ld && y >= 0 && y <= N && y < y_end);
+        bn = vload<V>(pb + (long)(y - 1) * pitch, ld && (y - 1) > 0 && (y - 1) < N && y <= y_end);
+    } else {
+        in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
+        bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
+    }
+}
+
 template <typename T, int K, int PRE, int POST, int SM, bool EDGE, int P>
 __device__ __forceinline__ void
 cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&bw)[K + 1],
+           typename VecOf<T>::type& nin, typename VecOf<T>::type& nbn,
            CycleState<T, VecOf<T>::W / 2>& cs, int y,
            const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
            const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
@@ -762,14 +796,11 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     const V Z = vzero((V*)nullptr);
     const int r0 = ca.r0, r1 = ca.r1;
 
-    V in, bn;
-    if (EDGE) {
-        in = vload<V>(pv + (long)y * pitch, ld && y >= bnd_lo && y <= bnd_hi && y < ca.y_end);
-        bn = vload<V>(pb + (long)(y - 1) * pitch, ld && (y - 1) > bnd_lo && (y - 1) < bnd_hi && y <= ca.y_end);
-    } else {
-        in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
-        bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
-    }
+    // input row y and rhs row y-1 were loaded during the previous step (software
+    // prefetch, see fused_step); issue the next step's loads before computing
+    V in = nin;
+    const V bn = nbn;
+    cycle_loads<T, EDGE>(nin, nbn, y + 1, pv, pb, pitch, N, ca.y_end, ld);
     if (PRE) {
         // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624)
         const int I = y >> 1;
@@ -900,10 +931,12 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     const int y0 = r0 - K - ETOP;
     ca.y_end = r1 + K + EBOT;                       // exclusive end of the steps that matter
     const int steps = (ca.y_end - y0 + 2) / 3 * 3;  // rounded up to whole rotations
+    V nin, nbn;
+    cycle_loads<T, EDGE>(nin, nbn, y0, pv, pb, pitch, N, ca.y_end, ld);
     for (int y = y0; y < y0 + steps; y += 3) {
-        cycle_step<T, K, PRE, POST, SM, EDGE, 0>(lev, bw, cs, y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
-        cycle_step<T, K, PRE, POST, SM, EDGE, 1>(lev, bw, cs, y + 1, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
-        cycle_step<T, K, PRE, POST, SM, EDGE, 2>(lev, bw, cs, y + 2, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
+        cycle_step<T, K, PRE, POST, SM, EDGE, 0>(lev, bw, nin, nbn, cs, y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
+        cycle_step<T, K, PRE, POST, SM, EDGE, 1>(lev, bw, nin, nbn, cs, y + 1, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
+        cycle_step<T, K, PRE, POST, SM, EDGE, 2>(lev, bw, nin, nbn, cs, y + 2, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
     }
     return cs.acc;
 }
@@ -934,10 +967,11 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         const bool st = (lane >= HL) && (lane < kWave - HL) && (vx < N / W);
         const int r0 = row_lo + t.chunk * R;
         const int r1 = min(r0 + R, row_hi);
-        // everything the unpredicated body touches (rows r0-K-ETOP-1 .. r1+K+EBOT+1, one vector
-        // beyond the first and last lane, the matching coarse rows/columns) strictly inside
+        // everything the unpredicated body touches (rows r0-K-ETOP-1 .. r1+K+EBOT+2: rotation
+        // rounding plus one prefetched row; one vector beyond the first and last lane; the
+        // matching coarse rows/columns) strictly inside
         const bool interior = (vx0 >= 1) && ((long)(vx0 + kWave + 1) * W < N) &&
-                              (r0 - K - ETOP - 1 > 0) && (r1 + K + EBOT + 2 < N);
+                              (r0 - K - ETOP - 1 > 0) && (r1 + K + EBOT + 3 < N);
         if (interior)
             acc = cycle_body<T, K, PRE, POST, SM, false>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
                                                          pitch, cpitch, col, N, r0, r1, true, st, c0, c1);

@@ -48,7 +48,7 @@ def mgs(pkg):
 
 
 @pytest.mark.parametrize("name", ["f64", "f32"])
-@pytest.mark.parametrize("level", [2, 3, 5, 6, 7, 8, 10])
+@pytest.mark.parametrize("level", [2, 3, 5, 6, 7, 8, 9, 10])
 def test_jacobi_matches_oracle(mgs, po, name, level):
     dt, _, tol = DT[name]
     n = (1 << level) - 1
@@ -61,7 +61,7 @@ def test_jacobi_matches_oracle(mgs, po, name, level):
 
 
 @pytest.mark.parametrize("name", ["f64", "f32"])
-@pytest.mark.parametrize("level", [2, 3, 5, 6, 7, 8, 10])
+@pytest.mark.parametrize("level", [2, 3, 5, 6, 7, 8, 9, 10])
 def test_rbgs_matches_oracle(mgs, po, name, level):
     dt, _, tol = DT[name]
     n = (1 << level) - 1
@@ -197,7 +197,7 @@ def test_fused_sweeps_are_bit_identical_to_single_sweeps(pkg, po, name, kmax, mo
     monkeypatch.setenv("MGX_FUSE_ROWS", "16")
     rng = np.random.default_rng(700 + kmax)
     with pkg.Multigrid(finest_level=11, coarsest_level=8, dtype=code, bottom=pkg.BOTTOM_SMOOTH) as mg:
-        for level in (8, 10, 11):
+        for level in (8, 9, 10, 11):
             n = (1 << level) - 1
             v = rng.uniform(-1, 1, (n, n)).astype(dt)
             f = rng.uniform(-1, 1, (n, n)).astype(dt)
