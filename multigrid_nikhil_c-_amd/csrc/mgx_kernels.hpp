@@ -762,6 +762,27 @@ struct CycleArgs {              // what the stages besides the smoother need (un
 };
 
 // one row step of k_jacobi_cycle at window-rotation phase P (see fused_step)
+// PRE: the coarse correction values one fine row needs: coarse row I = y>>1 (a) and, for
+// odd y, row I+1 (b); CW+1 columns each
+template <typename T, int CW> struct PreFetch { T a[CW + 1], b[CW + 1]; };
+
+template <typename T, bool EDGE>
+__device__ __forceinline__ void
+coarse_loads(PreFetch<T, VecOf<T>::W / 2>& pe, int y, const T* __restrict__ coarse_e, long cpitch, long ccol, int N, bool cld)
+{
+    constexpr int CW = VecOf<T>::W / 2;
+    const int I = y >> 1;
+    const bool cl = EDGE ? (cld && y > 0 && y < N) : true;
+    const T* p = coarse_e + (long)I * cpitch + ccol;
+#pragma unroll
+    for (int k = 0; k <= CW; ++k) pe.a[k] = cl ? p[k] : (T)0;
+    // the row below is only used by odd fine rows; loading it always keeps the step branch-free
+    const bool cl2 = EDGE ? (cl && (y & 1)) : true;
+    const T* q = p + cpitch;
+#pragma unroll
+    for (int k = 0; k <= CW; ++k) pe.b[k] = cl2 ? q[k] : (T)0;
+}
+
 // loads of one step of k_jacobi_cycle (whole grids: rows 0..N exist)
 template <typename T, bool EDGE>
 __device__ __forceinline__ void
@@ -781,7 +802,7 @@ cycle_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
 template <typename T, int K, int PRE, int POST, int SM, bool EDGE, int P>
 __device__ __forceinline__ void
 cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&bw)[K + 1],
-           typename VecOf<T>::type& nin, typename VecOf<T>::type& nbn,
+           typename VecOf<T>::type& nin, typename VecOf<T>::type& nbn, PreFetch<T, VecOf<T>::W / 2>& pe,
            CycleState<T, VecOf<T>::W / 2>& cs, int y,
            const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
            const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
@@ -802,22 +823,17 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     const V bn = nbn;
     cycle_loads<T, EDGE>(nin, nbn, y + 1, pv, pb, pitch, N, ca.y_end, ld);
     if (PRE) {
-        // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624)
-        const int I = y >> 1;
+        // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624).  The coarse
+        // values of row y were fetched during the previous step (pe.a = coarse row y>>1,
+        // pe.b = the row below it); fetch the next row's before using these.
         T a[CW + 1], b2[CW + 1], o[W];
-        const bool cl = EDGE ? (cld && y > bnd_lo && y < bnd_hi) : true;
-        {
-            const T* p = coarse_e + (long)I * ca.cpitch + ccol;
 #pragma unroll
-            for (int k = 0; k <= CW; ++k) a[k] = cl ? p[k] : (T)0;
-        }
+        for (int k = 0; k <= CW; ++k) { a[k] = pe.a[k]; b2[k] = pe.b[k]; }
+        coarse_loads<T, EDGE>(pe, y + 1, coarse_e, ca.cpitch, ccol, N, cld);
         if ((y & 1) == 0) {
 #pragma unroll
             for (int k = 0; k < CW; ++k) { o[2 * k] = a[k]; o[2 * k + 1] = (T)0.5 * (a[k] + a[k + 1]); }
         } else {
-            const T* p = coarse_e + (long)(I + 1) * ca.cpitch + ccol;
-#pragma unroll
-            for (int k = 0; k <= CW; ++k) b2[k] = cl ? p[k] : (T)0;
 #pragma unroll
             for (int k = 0; k < CW; ++k) {
                 o[2 * k] = (T)0.5 * (a[k] + b2[k]);
@@ -933,10 +949,14 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     const int steps = (ca.y_end - y0 + 2) / 3 * 3;  // rounded up to whole rotations
     V nin, nbn;
     cycle_loads<T, EDGE>(nin, nbn, y0, pv, pb, pitch, N, ca.y_end, ld);
+    PreFetch<T, CW> pe;
+#pragma unroll
+    for (int k = 0; k <= CW; ++k) { pe.a[k] = (T)0; pe.b[k] = (T)0; }
+    if (PRE) coarse_loads<T, EDGE>(pe, y0, coarse_e, cpitch, ccol, N, cld);
     for (int y = y0; y < y0 + steps; y += 3) {
-        cycle_step<T, K, PRE, POST, SM, EDGE, 0>(lev, bw, nin, nbn, cs, y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
-        cycle_step<T, K, PRE, POST, SM, EDGE, 1>(lev, bw, nin, nbn, cs, y + 1, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
-        cycle_step<T, K, PRE, POST, SM, EDGE, 2>(lev, bw, nin, nbn, cs, y + 2, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
+        cycle_step<T, K, PRE, POST, SM, EDGE, 0>(lev, bw, nin, nbn, pe, cs, y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
+        cycle_step<T, K, PRE, POST, SM, EDGE, 1>(lev, bw, nin, nbn, pe, cs, y + 1, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
+        cycle_step<T, K, PRE, POST, SM, EDGE, 2>(lev, bw, nin, nbn, pe, cs, y + 2, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
     }
     return cs.acc;
 }
