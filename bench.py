@@ -288,7 +288,19 @@ def main():
 
     ge.load_package()
     dist_bench = import_module("multigrid_nikhil_c_amd.dist_bench")
-    dist_bench.run(args, emit)
+    try:
+        dist_bench.run(args, emit)
+    except BaseException as e:       # noqa: BLE001 - report, then fail: the line is the only channel back
+        import traceback
+
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0:
+            emit({"metric": "fine_grid_stencil_updates_per_sec", "value": None, "unit": "updates/s",
+                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                  "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                  "config": {"workload": f"2D Poisson {1 << args.level}^2, row slabs over {world} GPUs"},
+                  "error": f"{type(e).__name__}: {e}"})
+        raise
 
 
 if __name__ == "__main__":

@@ -132,8 +132,6 @@ int prof_collect(mgx_solver* s)
 }
 
 // ---- typed operator launches ----------------------------------------------------
-template <typename T> constexpr int dtype_of() { return sizeof(T) == 8 ? MGX_DTYPE_F64 : MGX_DTYPE_F32; }
-
 template <typename T>
 void launch_jacobi(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
                    double omega, int rpc, hipStream_t st)

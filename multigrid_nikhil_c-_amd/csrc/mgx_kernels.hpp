@@ -1,14 +1,18 @@
 // mgx_kernels.hpp — hand-written gfx950 (CDNA4, wave64) stencil kernels for the
-// 2-D Poisson multigrid hot path.  Device code only; launch wrappers at the end.
+// 2-D Poisson multigrid hot path.  Device code only; launch geometry at the end.
 //
 // What each kernel replaces in the reference (PS = Poissons_SYCL.cpp,
 // MF = Multigrid_functions.cpp):
-//   k_jacobi          PS:137-145  (gemv + scal + scal + add + add per sweep; K1-K5)
-//   k_rbgs            -- absent from the reference; SURVEY §8a row A8
-//   k_residual        PS:604-607  (2 gemv + add + sub; K6-K9)
-//   k_restrict        PS:531-546  restriction2d (fused with the residual when FUSED)
-//   k_prolong         PS:337-425  interpolation2d, + PS:623 correction add (K10)
-//   k_norm2_*         -- the reference reports no residual (D10)
+//   k_jacobi_rows / k_jacobi   PS:137-145  one sweep (gemv + scal + scal + add + add; K1-K5)
+//   k_jacobi_fused<T,K,SM>     K levels per pass: K Jacobi sweeps (SM 0) or K/2 red-black
+//                              Gauss-Seidel sweeps (SM 1) - temporal fusion of PS:137-145
+//   k_jacobi_cycle<..PRE,POST> the same pass with the cycle's transfers folded in:
+//                              PS:620-624 correction on load, PS:604-613 residual +
+//                              restriction + zero guess, or the residual norm
+//   k_rbgs                     one red-black GS sweep (absent from the reference)
+//   k_residual                 PS:604-607  (2 gemv + add + sub; K6-K9), also sum r^2 (D10)
+//   k_restrict                 PS:531-546  restriction2d (fused with the residual when FUSED)
+//   k_prolong                  PS:337-425  interpolation2d, + PS:623 correction add (K10)
 //
 // Storage (DESIGN.md "Data layout in HBM"): one level = the full node grid,
 // rows 0..N and columns 0..N with N = 2^L, *including* the zero Dirichlet ring
@@ -16,15 +20,15 @@
 // so every row starts on a cache line; columns N+1..pitch-1 are zero padding.
 // A thread owns one 16-byte vector (2 doubles / 4 floats) of a row, a wave owns
 // 64 consecutive vectors, and every global access is a 16-byte access at a
-// 16-byte-aligned address.  Waves march down a chunk of rows keeping the
-// rolling row window in registers, so each value is read from HBM once; the
-// x-neighbours come from the adjacent lanes by wavefront shuffles, and the two
-// outermost lanes of a wave are halo lanes (they load and compute but never
-// store), which is what lets the red-black kernel update both colours in one
-// pass over the data.
+// 16-byte-aligned address.  The x-neighbours come from the adjacent lanes by DPP
+// wavefront shifts, and the outermost lanes of a wave are halo lanes (they load
+// and compute but never store), so no wave ever depends on another wave's
+// registers, LDS or output.  Multi-level kernels march down a chunk of rows
+// keeping rolling row windows in registers, so each value is read from HBM once
+// per pass whatever the number of sweeps the pass performs.
 //
-// All loads are predicated on explicit bounds derived from (N, pitch, rows):
-// no kernel here can address outside its arrays whatever the launch geometry.
+// All loads are bounded by (N, pitch, allocation height): no kernel here can
+// address outside its arrays whatever the launch geometry.
 #pragma once
 
 #include <hip/hip_runtime.h>
