@@ -214,6 +214,13 @@ inline int fuse_rows(const FuseCfg& fc, int N, int K)
     return R;
 }
 
+// smallest grid (N = 2^L) on which fused / folded passes replace single sweeps
+inline int fuse_min_n()
+{
+    static const int n = env_int("MGX_FUSE_MIN_N", 256);
+    return n < 64 ? 64 : n;
+}
+
 inline FuseCfg fuse_cfg()
 {
     FuseCfg f;
@@ -276,8 +283,8 @@ int smooth_block(int smoother, T* a, const T* rhs, T* b2, int N, long pitch, int
     int flips = 0;
     int done = 0;
     // Fused launches pay (R + 2K)/R redundant rows and need enough chunks to fill
-    // the chip: measured worthwhile from 512^2 up, with R growing with the grid.
-    const bool allow_fuse = fc.kmax > per && N >= 512 && (row_hi - row_lo) >= 64 && mu <= 64;
+    // the chip: measured worthwhile from 256^2 up, with R growing with the grid.
+    const bool allow_fuse = fc.kmax > per && N >= fuse_min_n() && (row_hi - row_lo) >= 64 && mu <= 64;
     std::vector<int> parts(mu > 0 ? mu : 1, 1);
     const int nparts = allow_fuse ? plan_fusion(mu, fc.kmax, sizeof(T) == 8, parts.data(), rbgs) : mu;
     const int bl = first - 1, bh = last;
@@ -585,7 +592,7 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
 // pre-check made before any launch (so a `false` never leaves a half-done block)
 bool fold_eligible(const mgx_solver* s, const Level& l, int mu)
 {
-    if (!s->fold || mu < 1 || mu > 64 || l.N < 512) return false;
+    if (!s->fold || mu < 1 || mu > 64 || l.N < fuse_min_n()) return false;
     const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
     const int per = rbgs ? 2 : 1;
     if (s->fuse.kmax < per) return false;
