@@ -246,6 +246,31 @@ def run_single(args):
         },
     }
     mg.close()
+    # ---- the HBM-bound regime, live: the same smoother with temporal fusion off
+    # (one k_jacobi_rows / k_rbgs launch per sweep moves exactly its algorithmic
+    # bytes), timed with HIP events on the solver's stream.  The fused passes
+    # above beat the roofline by reusing bytes; this is the roofline they start from.
+    try:
+        os.environ["MGX_FUSE"] = "1"
+        with pkg.Multigrid(**dict(cfg, profile=0)) as mg1:
+            mg1.fill_rhs(1, 0.0)
+            mg1.fill_guess_random(12345)
+            mg1.time_smoother(5)
+            sweeps1 = 30
+            ms1 = mg1.time_smoother(sweeps1)
+        a1 = 3.0 * es * n * n / (ms1 / sweeps1 * 1e-3) / 1e9
+        out["roofline_single_sweep"] = {
+            "bound": "hbm", "kernel": ("k_rbgs" if args.smoother == "rbgs" else "k_jacobi_rows") + f"<{tname}>",
+            "achieved": a1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS,
+            "frac_of_measured_copy_ceiling": a1 / HBM_COPY_CEILING_GBS,
+            "traffic": pmc_traffic(f"L{L}_{args.smoother}_{args.dtype}_mu1_unfused"),
+            "avg_launch_ms": ms1 / sweeps1, "launches_timed": sweeps1,
+            "how": "MGX_FUSE=1 handle, mgx_time_smoother: HIP events around 30 back-to-back sweeps",
+        }
+    except Exception as e:
+        out["roofline_single_sweep"] = {"error": str(e)}
+    finally:
+        os.environ.pop("MGX_FUSE", None)
     # ---- the reference's own problem and schedule (PS:123 f = 4, PS:630 zero guess,
     # PS:727 fullmultigrid), run to 1e-8: one FMG pass (mu0 = 0: one V-cycle per level)
     # followed by V-cycles.  Untimed part of the job; reported for the "V-cycles to 1e-8"

@@ -51,7 +51,9 @@ struct Level {
 
 struct EventPair { hipEvent_t a, b; int cls; long long launches; long long sweeps; };
 
-struct FuseCfg { int kmax; int rows; };   // temporal fusion of Jacobi sweeps (rows 0 = by grid size)
+// temporal fusion knobs: levels per pass, chunk height (0 = by grid size), smallest
+// fused grid, levels per pass for the folded kernels
+struct FuseCfg { int kmax; int rows; int min_n; int fold_kmax; };
 
 } // namespace
 
@@ -69,7 +71,7 @@ struct mgx_solver {
     double* sum_host = nullptr;     // pinned
     std::string err;
     int rows_per_chunk = 0;         // 0 = auto (MGX_ROWS env overrides)
-    FuseCfg fuse{10, 0};            // temporal fusion of Jacobi sweeps (MGX_FUSE, MGX_FUSE_ROWS)
+    FuseCfg fuse{10, 0, 256, 5};    // temporal fusion knobs (MGX_FUSE, MGX_FUSE_ROWS, MGX_FUSE_MIN_N, MGX_FOLD_KMAX)
     // profiling
     std::vector<EventPair> ev_used, ev_free;
     double prof_ms[MGX_PROF_COUNT] = {0};
@@ -214,13 +216,6 @@ inline int fuse_rows(const FuseCfg& fc, int N, int K)
     return R;
 }
 
-// smallest grid (N = 2^L) on which fused / folded passes replace single sweeps
-inline int fuse_min_n()
-{
-    static const int n = env_int("MGX_FUSE_MIN_N", 256);
-    return n < 64 ? 64 : n;
-}
-
 inline FuseCfg fuse_cfg()
 {
     FuseCfg f;
@@ -229,6 +224,13 @@ inline FuseCfg fuse_cfg()
     if (f.kmax > 10) f.kmax = 10;
     f.rows = env_int("MGX_FUSE_ROWS", 0);      // 0: chosen from the grid size
     if (f.rows < 0) f.rows = 0;
+    // smallest grid (N = 2^L) on which fused / folded passes replace single sweeps
+    f.min_n = std::max(64, env_int("MGX_FUSE_MIN_N", 256));
+    // Levels per pass for the folded kernels.  They carry one more level window and the
+    // transfer state, so their sweet spot is shallower than the plain fused kernel's and
+    // flat: measured in one process on one MI355X, V(10,10) at 8192^2 fp64 takes 2.63 ms as
+    // [5,5] and 2.62 as [10] (244-256 VGPRs, 2 waves/SIMD); [5,5] is better on smaller grids.
+    f.fold_kmax = std::max(1, std::min(f.kmax, env_int("MGX_FOLD_KMAX", 5)));
     return f;
 }
 
@@ -284,7 +286,7 @@ int smooth_block(int smoother, T* a, const T* rhs, T* b2, int N, long pitch, int
     int done = 0;
     // Fused launches pay (R + 2K)/R redundant rows and need enough chunks to fill
     // the chip: measured worthwhile from 256^2 up, with R growing with the grid.
-    const bool allow_fuse = fc.kmax > per && N >= fuse_min_n() && (row_hi - row_lo) >= 64 && mu <= 64;
+    const bool allow_fuse = fc.kmax > per && N >= fc.min_n && (row_hi - row_lo) >= 64 && mu <= 64;
     std::vector<int> parts(mu > 0 ? mu : 1, 1);
     const int nparts = allow_fuse ? plan_fusion(mu, fc.kmax, sizeof(T) == 8, parts.data(), rbgs) : mu;
     const int bl = first - 1, bh = last;
@@ -541,15 +543,7 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
 // (post = 1) or the residual norm (post = 2) produced by the last pass.
 // Returns false when this level / configuration is not eligible (caller then
 // uses the stand-alone kernels); on success *norm_blocks = partial sums written.
-// Levels per pass for the folded kernels.  They carry one more level window and the
-// transfer state, so their sweet spot is shallower than the plain fused kernel's:
-// measured on one MI355X in one process, V(10,10) at 8192^2 fp64 takes 2.67 ms as
-// [5,5], 2.84 as [6,4] and 2.82 as [10] (244-256 VGPRs, 2 waves/SIMD).
-inline int fold_kmax(const mgx_solver* s)
-{
-    static const int env = env_int("MGX_FOLD_KMAX", 5);
-    return std::max(1, std::min(s->fuse.kmax, env));
-}
+inline int fold_kmax(const mgx_solver* s) { return s->fuse.fold_kmax; }
 
 template <typename T, int SM>
 bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool pre, int post, int* launches,
@@ -592,7 +586,7 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
 // pre-check made before any launch (so a `false` never leaves a half-done block)
 bool fold_eligible(const mgx_solver* s, const Level& l, int mu)
 {
-    if (!s->fold || mu < 1 || mu > 64 || l.N < fuse_min_n()) return false;
+    if (!s->fold || mu < 1 || mu > 64 || l.N < s->fuse.min_n) return false;
     const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
     const int per = rbgs ? 2 : 1;
     if (s->fuse.kmax < per) return false;

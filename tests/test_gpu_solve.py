@@ -210,3 +210,26 @@ def test_folded_cycle_passes_are_bit_identical(pkg, po, monkeypatch, dtype, mu1,
     if dtype == 1:
         _, h_ref = po.Solver(**cfg).solve(b, u0, tol=0.0, max_cycles=3)
         assert hist_close(out["1"][0], h_ref), (out["1"][0], h_ref)
+
+
+@pytest.mark.parametrize("smoother", [0, 1])
+def test_tuning_knobs_never_change_a_bit(pkg, po, monkeypatch, smoother):
+    """MGX_* environment knobs select kernels (marching vs row kernel, fused depth, folding,
+    chunk height, fusion threshold); every combination must give the same bits"""
+    cfg = dict(finest_level=10, coarsest_level=7, mu1=4, mu2=3, schedule=0, smoother=smoother)
+    b = po.rhs_sine(10)
+    u0 = po.fill_uniform(b.shape, 5)
+    knobs = [{}, {"MGX_FUSE": "1"}, {"MGX_FUSE": "1", "MGX_ROWS": "8"}, {"MGX_FOLD": "0"},
+             {"MGX_FOLD_KMAX": "10", "MGX_FUSE_ROWS": "16"}, {"MGX_FUSE_MIN_N": "1024"}, {"MGX_FUSE": "2", "MGX_FUSE_MIN_N": "128"}]
+    ref = None
+    for kn in knobs:
+        for k in ("MGX_FUSE", "MGX_ROWS", "MGX_FOLD", "MGX_FOLD_KMAX", "MGX_FUSE_ROWS", "MGX_FUSE_MIN_N"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in kn.items():
+            monkeypatch.setenv(k, v)
+        st, h, u = run_gpu(pkg, cfg, b, u0, tol=0.0, max_cycles=2)
+        if ref is None:
+            ref = u
+            _, h_orc = po.Solver(**cfg).solve(b, u0, tol=0.0, max_cycles=2)
+            assert hist_close(h, h_orc)
+        assert np.array_equal(u, ref), kn
