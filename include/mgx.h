@@ -92,6 +92,15 @@ enum { MGX_VEC_U = 0, MGX_VEC_B = 1, MGX_VEC_R = 2 };
 /* Right-hand side of the finest level: replaces globalforcefunction()'s
  * output handed to fullmultigrid (PS:725-727).  count must be n*n. */
 MGX_API int mgx_set_rhs(mgx_handle h, const void* b, size_t count);
+/* Right-hand side with non-homogeneous Dirichlet data folded in (the general
+ * input path of SURVEY §8f: the reference hard-wires u = 0 on the boundary by
+ * eliminating the boundary nodes, PS:188-198, 224).  `ring` holds the boundary
+ * node values g in the order: row 0 (columns 0..N), row N (columns 0..N),
+ * column 0 (rows 1..N-1), column N (rows 1..N-1); ring_count = 4 N, N = n + 1.
+ * Because every off-diagonal of A is -1, eliminating a boundary neighbour moves
+ * +g to the right-hand side: b_ij += sum of its boundary neighbours' g.  The
+ * solve then returns the interior of the solution of  A u = b,  u = g on the ring. */
+MGX_API int mgx_set_rhs_dirichlet(mgx_handle h, const void* b, size_t count, const void* ring, size_t ring_count);
 /* Initial guess / result of the finest level (PS:630 starts from zero). */
 MGX_API int mgx_set_guess(mgx_handle h, const void* u, size_t count);
 MGX_API int mgx_get_solution(mgx_handle h, void* u, size_t count);

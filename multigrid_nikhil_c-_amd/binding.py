@@ -30,7 +30,7 @@ PROF_SMOOTH_FINE, PROF_RESTRICT_FINE, PROF_PROLONG_FINE, PROF_NORM_FINE, PROF_CO
 # every symbol include/mgx.h declares (tests check the library exports them all)
 EXPORTS = [
     "mgx_config_default", "mgx_create", "mgx_destroy", "mgx_last_error", "mgx_status_string",
-    "mgx_level_n", "mgx_set_rhs", "mgx_set_guess", "mgx_get_solution", "mgx_set_level",
+    "mgx_level_n", "mgx_set_rhs", "mgx_set_rhs_dirichlet", "mgx_set_guess", "mgx_get_solution", "mgx_set_level",
     "mgx_get_level", "mgx_set_level_device", "mgx_get_level_device", "mgx_zero_level", "mgx_fill_rhs", "mgx_fill_guess_random", "mgx_smooth", "mgx_residual",
     "mgx_restrict", "mgx_restrict_rhs", "mgx_prolong_add", "mgx_prolong", "mgx_bottom_solve",
     "mgx_residual_norm", "mgx_vcycle", "mgx_fmg", "mgx_solve", "mgx_profile_reset",
@@ -98,6 +98,7 @@ def lib() -> C.CDLL:
     L.mgx_level_pitch.restype = C.c_long
     for name in ("mgx_set_rhs", "mgx_set_guess", "mgx_get_solution"):
         getattr(L, name).argtypes = [vp, vp, C.c_size_t]
+    L.mgx_set_rhs_dirichlet.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
     L.mgx_set_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
     L.mgx_get_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
     L.mgx_set_level_device.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -203,6 +204,15 @@ class Multigrid:
 
     def set_rhs(self, b):
         self.set_level(self.cfg.finest_level, VEC_B, b)
+
+    def set_rhs_dirichlet(self, b, g_top, g_bottom, g_left, g_right):
+        """right-hand side with boundary values folded in: g_top/g_bottom are rows 0 and N
+        (N+1 values each), g_left/g_right columns 0 and N on rows 1..N-1"""
+        dt = self.level_dtype(self.cfg.finest_level, VEC_B)
+        b = np.ascontiguousarray(b, dtype=dt)
+        ring = np.ascontiguousarray(np.concatenate([g_top, g_bottom, g_left, g_right]), dtype=dt)
+        self._chk(lib().mgx_set_rhs_dirichlet(self._h, b.ctypes.data, b.size, ring.ctypes.data, ring.size),
+                  "mgx_set_rhs_dirichlet")
 
     def set_guess(self, u):
         self.set_level(self.cfg.finest_level, VEC_U, u)

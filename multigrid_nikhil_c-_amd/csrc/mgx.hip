@@ -765,6 +765,24 @@ Level* pick(mgx_solver* s, int level, int which, void** grid)
     return l;
 }
 
+// non-homogeneous Dirichlet data: b_ij += g of the boundary neighbours (mgx_set_rhs_dirichlet)
+template <typename T>
+void fold_ring(std::vector<T>& b, const T* ring, size_t n)
+{
+    const size_t N = n + 1;
+    const T* top = ring;                 // row 0, columns 0..N
+    const T* bot = ring + (N + 1);       // row N, columns 0..N
+    const T* lef = ring + 2 * (N + 1);   // column 0, rows 1..N-1
+    const T* rig = lef + (N - 1);        // column N, rows 1..N-1
+    for (size_t j = 0; j < n; ++j) {
+        b[j] += top[j + 1];                          // interior row 1 touches boundary row 0
+        b[(n - 1) * n + j] += bot[j + 1];            // interior row N-1 touches boundary row N
+    }
+    for (size_t i = 0; i < n; ++i) {
+        b[i * n] += lef[i];                          // interior column 1 touches boundary column 0
+        b[i * n + (n - 1)] += rig[i];
+    }
+}
 } // namespace
 
 // =====================================================================================
@@ -974,6 +992,24 @@ int mgx_zero_level(mgx_handle s, int level, int which)
 }
 
 int mgx_set_rhs(mgx_handle s, const void* b, size_t count) { return s ? mgx_set_level(s, s->cfg.finest_level, MGX_VEC_B, b, count) : MGX_ERR_INVALID; }
+int mgx_set_rhs_dirichlet(mgx_handle s, const void* b, size_t count, const void* ring, size_t ring_count)
+{
+    if (!s || !b || !ring) return MGX_ERR_INVALID;
+    const int L = s->cfg.finest_level;
+    const size_t n = (size_t)((1 << L) - 1);
+    if (count != n * n) return s->fail(MGX_ERR_INVALID, "vector length must be n*n with n = 2^level - 1");
+    if (ring_count != 4 * (n + 1)) return s->fail(MGX_ERR_INVALID, "ring must hold 4 N boundary values, N = n + 1");
+    const bool f64 = (s->cfg.dtype != MGX_DTYPE_F32);
+    if (f64) {
+        std::vector<double> t((const double*)b, (const double*)b + count);
+        fold_ring<double>(t, (const double*)ring, n);
+        return mgx_set_level(s, L, MGX_VEC_B, t.data(), count);
+    }
+    std::vector<float> t((const float*)b, (const float*)b + count);
+    fold_ring<float>(t, (const float*)ring, n);
+    return mgx_set_level(s, L, MGX_VEC_B, t.data(), count);
+}
+
 int mgx_set_guess(mgx_handle s, const void* u, size_t count) { return s ? mgx_set_level(s, s->cfg.finest_level, MGX_VEC_U, u, count) : MGX_ERR_INVALID; }
 int mgx_get_solution(mgx_handle s, void* u, size_t count) { return s ? mgx_get_level(s, s->cfg.finest_level, MGX_VEC_U, u, count) : MGX_ERR_INVALID; }
 

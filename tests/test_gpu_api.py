@@ -109,3 +109,27 @@ def test_other_smoother_precision_schedule_combinations(pkg, po, cfg):
     keep = h_ref > 1e-4 * h_ref[0] if cfg["dtype"] == 0 else np.ones(len(h_ref), bool)
     assert np.all(np.abs(h[keep] - h_ref[keep]) <= tol * h_ref[keep] + 1e-13 * h_ref[0]), (h, h_ref)
     assert np.max(np.abs(u - u_ref)) <= (1e-4 if cfg["dtype"] == 0 else 1e-8) * np.max(np.abs(u_ref))
+
+
+def test_nonzero_dirichlet_data_known_answer(pkg, po):
+    """u = x^2 - y^2 is harmonic and the 5-point Laplacian is exact for quadratics, so with
+    f = 0 and g = u on the boundary the discrete solution IS u at the nodes (to rounding)."""
+    level = 9
+    N = 1 << level
+    x = np.arange(N + 1) / N
+    U = x[None, :] ** 2 - x[:, None] ** 2             # rows = y, columns = x
+    with pkg.Multigrid(finest_level=level, coarsest_level=6, mu1=2, mu2=2, schedule=0, smoother=1) as mg:
+        mg.set_rhs_dirichlet(np.zeros((N - 1, N - 1)), U[0, :], U[N, :], U[1:N, 0], U[1:N, N])
+        st, h = mg.solve(tol=1e-13, max_cycles=30)
+        u = mg.get_solution()
+    assert st.converged
+    assert np.max(np.abs(u - U[1:N, 1:N])) < 1e-11
+    # and the folding itself against a numpy statement
+    b = np.zeros((N - 1, N - 1))
+    b[0, :] += U[0, 1:N]; b[-1, :] += U[N, 1:N]; b[:, 0] += U[1:N, 0]; b[:, -1] += U[1:N, N]
+    with pkg.Multigrid(finest_level=level, coarsest_level=6) as mg:
+        mg.set_rhs_dirichlet(np.zeros((N - 1, N - 1)), U[0, :], U[N, :], U[1:N, 0], U[1:N, N])
+        assert np.array_equal(mg.get_level(level, pkg.VEC_B), b)
+        with pytest.raises(pkg.MgxError, match="ring"):
+            pkg.lib()  # keep lib loaded
+            mg._chk(pkg.lib().mgx_set_rhs_dirichlet(mg._h, b.ctypes.data, b.size, b.ctypes.data, 7), "mgx_set_rhs_dirichlet")
