@@ -79,6 +79,8 @@ struct mgx_solver {
     long long prof_sweeps[MGX_PROF_COUNT] = {0};
     int last_smooth_launches = 0;   // launches made by the most recent smoothing block
     int fold = 1;                   // fold transfers / norm into smoother passes (MGX_FOLD)
+    int use_zero_in = 1;            // let first passes synthesise a known-zero iterate (MGX_ZERO_IN)
+    int zero_in_level = -1;         // level whose U is known to be all zero and has NOT been zero-filled
     bool want_norm = false;         // the top-level post-smoothing should also produce ||r||^2 partials
     int norm_blocks_ready = 0;      // > 0: partial[] holds that many sums of r^2 for the current U
     double fine_updates = 0.0;
@@ -170,7 +172,7 @@ void launch_rbgs(const T* vin, const T* b, T* vout, int N, long pitch, int row_l
 // red-black Gauss-Seidel sweeps (SM = 1)
 template <typename T, int K, int SM>
 void launch_fused_k(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
-                    T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st, int rows_alloc)
+                    T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st, int rows_alloc, int zero_in)
 {
     constexpr int OUT = fused_out_lanes<K, VecOf<T>::W>();
     Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, R);
@@ -178,26 +180,26 @@ void launch_fused_k(const T* vin, const T* b, T* vout, int N, long pitch, int ro
     const long waves = (long)g.strips * g.chunks;
     g.blocks = (int)(((waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
     hipLaunchKernelGGL((k_jacobi_fused<T, K, SM>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
-                       row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, bnd_lo, bnd_hi, row_parity, rows_alloc);
+                       row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, bnd_lo, bnd_hi, row_parity, rows_alloc, zero_in);
 }
 
 // rows_alloc: number of rows the arrays hold (every load is bounded by it)
 template <typename T, int SM>
 bool launch_fused(int K, const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
-                  T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st, int rows_alloc)
+                  T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st, int rows_alloc, int zero_in = 0)
 {
     switch (K) {
-        case 2: launch_fused_k<T, 2, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
-        case 4: launch_fused_k<T, 4, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
-        case 6: launch_fused_k<T, 6, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
-        case 8: launch_fused_k<T, 8, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
-        case 10: launch_fused_k<T, 10, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
+        case 2: launch_fused_k<T, 2, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
+        case 4: launch_fused_k<T, 4, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
+        case 6: launch_fused_k<T, 6, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
+        case 8: launch_fused_k<T, 8, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
+        case 10: launch_fused_k<T, 10, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
         default: break;
     }
     if constexpr (SM == 0) {
         switch (K) {
-            case 3: launch_fused_k<T, 3, 0>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
-            case 5: launch_fused_k<T, 5, 0>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc); return true;
+            case 3: launch_fused_k<T, 3, 0>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
+            case 5: launch_fused_k<T, 5, 0>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
             default: break;
         }
     }
@@ -327,6 +329,7 @@ struct FoldArgs {
     int restrict_mode = 0;
     double* partial = nullptr;        // POST 2: per-block sums of r^2
     long cpitch = 0;
+    int zero_in = 0;                  // the input iterate is all zero: the pass does not read it
 };
 
 template <typename T, int K, int PRE, int POST, int SM>
@@ -342,7 +345,7 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
     hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout,
                        (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
-                       1, N, g.R, g.strips, g.chunks, c0, c1);
+                       1, N, g.R, g.strips, g.chunks, c0, c1, fa.zero_in);
     return g.blocks;
 }
 
@@ -547,7 +550,7 @@ inline int fold_kmax(const mgx_solver* s) { return s->fuse.fold_kmax; }
 
 template <typename T, int SM>
 bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool pre, int post, int* launches,
-                     int* norm_blocks)
+                     int* norm_blocks, bool zero_in)
 {
     constexpr bool rbgs = (SM == 1);
     constexpr int per = rbgs ? 2 : 1;
@@ -559,7 +562,11 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
     FoldArgs fa;
     fa.restrict_mode = s->cfg.restrict_mode;
     fa.partial = s->partial;
-    if (coarse) { fa.cpitch = coarse->pitch; fa.coarse_e = coarse->u; fa.coarse_b = coarse->b; fa.coarse_zero = coarse->u; }
+    if (coarse) {
+        fa.cpitch = coarse->pitch; fa.coarse_e = coarse->u; fa.coarse_b = coarse->b;
+        // PS:613: zero the coarse guess here unless its first pre-smoothing pass synthesises it
+        fa.coarse_zero = (post == 1 && s->zero_in_level == coarse->L) ? nullptr : coarse->u;
+    }
     T* src = (T*)l.u; T* dst = (T*)l.tmp;
     const T* b = (const T*)l.b;
     for (int p = 0; p < np; ++p) {
@@ -568,13 +575,14 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
         const int Q = last ? post : 0;
         const int K = per * parts[p];
         const int R = fuse_rows(s->fuse, l.N, K);
+        fa.zero_in = (first && zero_in) ? 1 : 0;
         int blocks = 0;
         if (P && Q == 2) blocks = launch_cycle<T, 1, 2, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
         else if (P) blocks = launch_cycle<T, 1, 0, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
         else if (Q == 1) blocks = launch_cycle<T, 0, 1, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
         else if (Q == 2) blocks = launch_cycle<T, 0, 2, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
         else if (!rbgs && K == 1) launch_jacobi<T>(src, b, dst, l.N, l.pitch, 1, l.N, s->cfg.omega, s->rows_per_chunk, s->stream);
-        else (void)launch_fused<T, SM>(K, src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, 0, R, s->stream, l.rows);
+        else (void)launch_fused<T, SM>(K, src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, 0, R, s->stream, l.rows, fa.zero_in);
         if (Q == 2) *norm_blocks = blocks;
         std::swap(src, dst);
     }
@@ -598,7 +606,22 @@ bool fold_eligible(const mgx_solver* s, const Level& l, int mu)
     return true;
 }
 
-bool smooth_folded(mgx_solver* s, int level, int mu, bool pre, int post)
+// May the pre-smoothing of `level` start from an implicit zero iterate (the producer then
+// skips the zero fill)?  Only when its first pass is a kernel that honours zero_in: a folded
+// or fused pass, not a stand-alone single sweep.
+bool zero_in_ok(const mgx_solver* s, int level)
+{
+    if (!s->use_zero_in || level <= s->cfg.coarsest_level) return false;
+    const Level& l = s->lv[level];
+    const int mu = s->cfg.mu1;
+    if (!fold_eligible(s, l, mu)) return false;
+    const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
+    int parts[64];
+    const int np = plan_fusion(mu, fold_kmax(s), l.f64, parts, rbgs);
+    return !(np >= 2 && !rbgs && parts[0] == 1);      // a leading plain single Jacobi sweep reads its input
+}
+
+bool smooth_folded(mgx_solver* s, int level, int mu, bool pre, int post, bool zero_in = false)
 {
     Level& l = s->lv[level];
     if (!fold_eligible(s, l, mu)) return false;
@@ -608,10 +631,10 @@ bool smooth_folded(mgx_solver* s, int level, int mu, bool pre, int post)
     int launches = 0, nb = 0;
     const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
     bool ok;
-    if (l.f64) ok = rbgs ? smooth_folded_t<double, 1>(s, l, mu, coarse, pre, post, &launches, &nb)
-                         : smooth_folded_t<double, 0>(s, l, mu, coarse, pre, post, &launches, &nb);
-    else ok = rbgs ? smooth_folded_t<float, 1>(s, l, mu, coarse, pre, post, &launches, &nb)
-                   : smooth_folded_t<float, 0>(s, l, mu, coarse, pre, post, &launches, &nb);
+    if (l.f64) ok = rbgs ? smooth_folded_t<double, 1>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
+                         : smooth_folded_t<double, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in);
+    else ok = rbgs ? smooth_folded_t<float, 1>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
+                   : smooth_folded_t<float, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in);
     if (!ok) return false;
     p.set(launches, mu);
     if (post == 2) s->norm_blocks_ready = nb;
@@ -667,6 +690,8 @@ void bottom_solve(mgx_solver* s)
     else s->bottom.solve<float>((const float*)l.b, (float*)l.u, l.pitch, s->stream);
 }
 
+int zero_u(mgx_solver* s, int level);
+
 // PS:575-627 / MF:132-173
 void vcycle(mgx_solver* s, int level)
 {
@@ -679,11 +704,19 @@ void vcycle(mgx_solver* s, int level)
         }
         return;
     }
+    // Is this level's own iterate a known, not materialised, zero (set by the caller)?
+    const bool zin_here = (s->zero_in_level == level);
+    s->zero_in_level = -1;
+    // PS:613: the coarse guess is zero.  If the coarse level's first pass can synthesise it,
+    // nobody writes or reads those zeros.
+    const bool zin_next = zero_in_ok(s, level - 1);
+    if (zin_next) s->zero_in_level = level - 1;
     // PS:581 pre-smoothing + PS:604-613 residual, restriction, zero coarse guess:
     // one set of passes when the level is eligible for folding
-    if (!smooth_folded(s, level, s->cfg.mu1, false, 1)) {
+    if (!smooth_folded(s, level, s->cfg.mu1, false, 1, zin_here)) {
+        if (zin_here) (void)zero_u(s, level);                 // cannot happen (zero_in_ok == fold_eligible); stay correct
         smooth(s, level, s->cfg.mu1);                         // PS:581
-        restrict_level(s, level, true, true);                 // PS:604-613
+        restrict_level(s, level, true, !zin_next);            // PS:604-613
     }
     const bool top_norm = s->want_norm && level == s->cfg.finest_level;
     s->want_norm = false;                                     // only the outermost level reports the norm
@@ -712,11 +745,11 @@ int fmg(mgx_solver* s)
     } else {
         int rc = zero_u(s, lo);                                              // PS:630
         if (rc) return rc;
-        for (int i = 0; i <= s->cfg.mu0; ++i) vcycle(s, lo);                 // PS:635
+        for (int i = 0; i <= s->cfg.mu0; ++i) { s->zero_in_level = -1; vcycle(s, lo); }   // PS:635
     }
     for (int l = lo + 1; l <= hi; ++l) {
         prolong_level(s, l, false);                                          // PS:645
-        for (int i = 0; i <= s->cfg.mu0; ++i) vcycle(s, l);                  // PS:646-648
+        for (int i = 0; i <= s->cfg.mu0; ++i) { s->zero_in_level = -1; vcycle(s, l); }    // PS:646-648
     }
     return MGX_OK;
 }
@@ -865,6 +898,7 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
     s->rows_per_chunk = env_int("MGX_ROWS", 0);
     s->fuse = fuse_cfg();
     s->fold = env_int("MGX_FOLD", 1);
+    s->use_zero_in = env_int("MGX_ZERO_IN", 1);
     int rc = MGX_OK;
     auto bail = [&](int code) { g_create_error = s->err; mgx_destroy(s); return code; };
     if (hipStreamCreate(&s->stream) != hipSuccess) { s->err = "hipStreamCreate failed"; return bail(MGX_ERR_HIP); }
@@ -1121,6 +1155,7 @@ int mgx_residual_norm(mgx_handle s, int level, double* out)
 int mgx_vcycle(mgx_handle s, int level)
 {
     OP_PROLOGUE(s->cfg.coarsest_level)
+    s->zero_in_level = -1;
     vcycle(s, level);
     OP_EPILOGUE
 }
@@ -1156,7 +1191,7 @@ int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double
             if (hist[k] <= tol * hist[0]) break;
             s->norm_blocks_ready = 0;
             if (k == 0 && do_fmg) { if ((rc = fmg(s))) return rc; }
-            else { s->want_norm = true; vcycle(s, L); s->want_norm = false; }
+            else { s->want_norm = true; s->zero_in_level = -1; vcycle(s, L); s->want_norm = false; }
             if ((rc = residual_norm_grid(s, l, l.u, l.b, &r, MGX_PROF_NORM_FINE))) return rc;
             hist.push_back(r);
         }
@@ -1191,7 +1226,9 @@ int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double
                     launch_residual<double, 2>((const double*)d.u, (const double*)d.b, w.b, w.pitch, s->partial,
                                                s->sum_dev, 1.0 / scale, d.N, d.pitch, 1, d.N, rpc, s->stream, s->partial_cap);
                 }
-                HIPCHK(s, hipMemsetAsync(w.u, 0, w.bytes, s->stream));          // PS:613-style zero guess
+                // PS:613-style zero guess: implicit when the first pass can synthesise it
+                if (zero_in_ok(s, L)) s->zero_in_level = L;
+                else HIPCHK(s, hipMemsetAsync(w.u, 0, w.bytes, s->stream));
                 vcycle(s, L);
                 hipLaunchKernelGGL(k_axpy_f32_to_f64, dim3(g.blocks), dim3(kBlock), 0, s->stream, (double*)d.u,
                                    (const float*)w.u, scale, d.N, d.pitch, w.pitch, 1, d.N, g.R, g.strips, g.chunks, 0);

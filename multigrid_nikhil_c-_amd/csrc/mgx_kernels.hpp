@@ -373,18 +373,20 @@ template <typename T, int K, bool EDGE>
 __device__ __forceinline__ void
 fused_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
             const T* __restrict__ pv, const T* __restrict__ pb, long pitch, int r0, int r1, bool ld,
-            int bnd_lo, int bnd_hi, int rd_lo, int rd_hi)
+            int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, bool zero_in)
 {
     using V = typename VecOf<T>::type;
     if (EDGE) {
-        // [rd_lo, rd_hi]: rows inside the allocation and not beyond a boundary row
-        in = vload<V>(pv + (long)y * pitch, ld && y >= rd_lo && y <= rd_hi && y < r1 + K);
+        // [rd_lo, rd_hi]: rows inside the allocation and not beyond a boundary row;
+        // zero_in: the input is known to be all zero (PS:613 coarse guess): do not read it
+        in = vload<V>(pv + (long)y * pitch, ld && !zero_in && y >= rd_lo && y <= rd_hi && y < r1 + K);
         // rhs rows are needed only where some level is: [r0-K+1, r1+K-1)
         bn = vload<V>(pb + (long)(y - 1) * pitch,
                       ld && (y - 1) > bnd_lo && (y - 1) < bnd_hi && (y - 1) >= rd_lo && (y - 1) <= rd_hi &&
                       y >= r0 - K + 2 && y < r1 + K);
     } else {
-        in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
+        in = vzero((V*)nullptr);
+        if (!zero_in) in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
         bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
     }
 }
@@ -394,7 +396,7 @@ __device__ __forceinline__ void
 fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K],
            typename VecOf<T>::type& nin, typename VecOf<T>::type& nbn, int y,
            const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po, long pitch, long col, int N,
-           int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int par_c)
+           int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int par_c, bool zero_in)
 {
     using V = typename VecOf<T>::type;
     constexpr int S_OLD = (P + 1) % 3, S_MID = (P + 2) % 3, S_NEW = P;
@@ -403,7 +405,7 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
     // (software prefetch: on small grids there is ~1 wave per CU and nothing else
     // hides the load latency); issue the next step's loads before computing
     const V in = nin, bn = nbn;
-    fused_loads<T, K, EDGE>(nin, nbn, y + 1, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi);
+    fused_loads<T, K, EDGE>(nin, nbn, y + 1, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
 #pragma unroll
     for (int j = K - 1; j > 0; --j) bw[j] = bw[j - 1];
     bw[0] = bn;
@@ -425,7 +427,7 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
 template <typename T, int K, int SM, bool EDGE>
 __device__ __forceinline__ void
 fused_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po, long pitch, long col, int N,
-           int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int row_parity)
+           int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int row_parity, bool zero_in)
 {
     using V = typename VecOf<T>::type;
     const V Z = vzero((V*)nullptr);
@@ -441,11 +443,11 @@ fused_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     const int y0 = r0 - K;
     const int steps = (r1 + K - y0 + 2) / 3 * 3;
     V nin, nbn;
-    fused_loads<T, K, EDGE>(nin, nbn, y0, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi);
+    fused_loads<T, K, EDGE>(nin, nbn, y0, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
     for (int y = y0; y < y0 + steps; y += 3) {
-        fused_step<T, K, SM, EDGE, 0>(lev, bw, nin, nbn, y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c);
-        fused_step<T, K, SM, EDGE, 1>(lev, bw, nin, nbn, y + 1, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c);
-        fused_step<T, K, SM, EDGE, 2>(lev, bw, nin, nbn, y + 2, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c);
+        fused_step<T, K, SM, EDGE, 0>(lev, bw, nin, nbn, y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
+        fused_step<T, K, SM, EDGE, 1>(lev, bw, nin, nbn, y + 1, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
+        fused_step<T, K, SM, EDGE, 2>(lev, bw, nin, nbn, y + 2, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
     }
 }
 
@@ -453,7 +455,7 @@ template <typename T, int K, int SM = 0>
 __global__ void __launch_bounds__(kBlock)
 k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
                int N, long pitch, int row_lo, int row_hi, int R, int strips, int chunks,
-               T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int rows_alloc)
+               T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int rows_alloc, int zero_in)
 {
     constexpr int W = VecOf<T>::W;
     constexpr int HL = (K + W - 1) / W;           // halo lanes per side
@@ -480,8 +482,8 @@ k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     const bool interior = (vx0 >= 1) && ((long)(vx0 + kWave) * W < N) &&
                           (r0 - K - 1 > bnd_lo) && (r0 - K - 1 >= 0) &&
                           (r1 + K + 3 < bnd_hi) && (r1 + K + 3 <= rows_alloc - 1);
-    if (interior) fused_body<T, K, SM, false>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity);
-    else fused_body<T, K, SM, true>(pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity);
+    if (interior) fused_body<T, K, SM, false>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, zero_in != 0);
+    else fused_body<T, K, SM, true>(pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, zero_in != 0);
 }
 
 template <int K, int W> constexpr int fused_out_lanes() { return kWave - 2 * ((K + W - 1) / W); }
@@ -763,6 +765,7 @@ template <typename T, int CW> struct CycleState {
 struct CycleArgs {              // what the stages besides the smoother need (uniform)
     long cpitch; int NC;
     int r0, r1, y_end;
+    bool zero_in;               // the input iterate is all zero: do not read it
 };
 
 // one row step of k_jacobi_cycle at window-rotation phase P (see fused_step)
@@ -791,14 +794,15 @@ coarse_loads(PreFetch<T, VecOf<T>::W / 2>& pe, int y, const T* __restrict__ coar
 template <typename T, bool EDGE>
 __device__ __forceinline__ void
 cycle_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
-            const T* __restrict__ pv, const T* __restrict__ pb, long pitch, int N, int y_end, bool ld)
+            const T* __restrict__ pv, const T* __restrict__ pb, long pitch, int N, int y_end, bool ld, bool zero_in)
 {
     using V = typename VecOf<T>::type;
     if (EDGE) {
-        in = vload<V>(pv + (long)y * pitch, ld && y >= 0 && y <= N && y < y_end);
+        in = vload<V>(pv + (long)y * pitch, ld && !zero_in && y >= 0 && y <= N && y < y_end);
         bn = vload<V>(pb + (long)(y - 1) * pitch, ld && (y - 1) > 0 && (y - 1) < N && y <= y_end);
     } else {
-        in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
+        in = vzero((V*)nullptr);
+        if (!zero_in) in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
         bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
     }
 }
@@ -825,7 +829,7 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     // prefetch, see fused_step); issue the next step's loads before computing
     V in = nin;
     const V bn = nbn;
-    cycle_loads<T, EDGE>(nin, nbn, y + 1, pv, pb, pitch, N, ca.y_end, ld);
+    cycle_loads<T, EDGE>(nin, nbn, y + 1, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in);
     if (PRE) {
         // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624).  The coarse
         // values of row y were fetched during the previous step (pe.a = coarse row y>>1,
@@ -925,7 +929,7 @@ template <typename T, int K, int PRE, int POST, int SM, bool EDGE>
 __device__ __forceinline__ double
 cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
            const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
-           long pitch, long cpitch, long col, int N, int r0, int r1, bool ld, bool st, T c0, T c1)
+           long pitch, long cpitch, long col, int N, int r0, int r1, bool ld, bool st, T c0, T c1, bool zero_in)
 {
     using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
@@ -947,12 +951,12 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
         cs.ml[k] = cs.mc[k] = cs.mr[k] = (T)0;
     }
     CycleArgs ca;
-    ca.cpitch = cpitch; ca.NC = N / 2; ca.r0 = r0; ca.r1 = r1;
+    ca.cpitch = cpitch; ca.NC = N / 2; ca.r0 = r0; ca.r1 = r1; ca.zero_in = zero_in;
     const int y0 = r0 - K - ETOP;
     ca.y_end = r1 + K + EBOT;                       // exclusive end of the steps that matter
     const int steps = (ca.y_end - y0 + 2) / 3 * 3;  // rounded up to whole rotations
     V nin, nbn;
-    cycle_loads<T, EDGE>(nin, nbn, y0, pv, pb, pitch, N, ca.y_end, ld);
+    cycle_loads<T, EDGE>(nin, nbn, y0, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in);
     PreFetch<T, CW> pe;
 #pragma unroll
     for (int k = 0; k <= CW; ++k) { pe.a[k] = (T)0; pe.b[k] = (T)0; }
@@ -971,7 +975,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
                const T* __restrict__ coarse_e,                       // PRE
                T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,   // POST == 1
                double* __restrict__ partial,                          // POST == 2
-               int N, long pitch, long cpitch, int row_lo, int row_hi, int R, int strips, int chunks, T c0, T c1)
+               int N, long pitch, long cpitch, int row_lo, int row_hi, int R, int strips, int chunks, T c0, T c1, int zero_in)
 {
     constexpr int W = VecOf<T>::W;
     constexpr int XC = cycle_halo_cols<K, POST>();
@@ -998,10 +1002,10 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
                               (r0 - K - ETOP - 1 > 0) && (r1 + K + EBOT + 3 < N);
         if (interior)
             acc = cycle_body<T, K, PRE, POST, SM, false>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
-                                                         pitch, cpitch, col, N, r0, r1, true, st, c0, c1);
+                                                         pitch, cpitch, col, N, r0, r1, true, st, c0, c1, zero_in != 0);
         else
             acc = cycle_body<T, K, PRE, POST, SM, true>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
-                                                        pitch, cpitch, col, N, r0, r1, ld, st, c0, c1);
+                                                        pitch, cpitch, col, N, r0, r1, ld, st, c0, c1, zero_in != 0);
     }
     if (POST == 2) {
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);

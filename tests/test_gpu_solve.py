@@ -220,10 +220,11 @@ def test_tuning_knobs_never_change_a_bit(pkg, po, monkeypatch, smoother):
     b = po.rhs_sine(10)
     u0 = po.fill_uniform(b.shape, 5)
     knobs = [{}, {"MGX_FUSE": "1"}, {"MGX_FUSE": "1", "MGX_ROWS": "8"}, {"MGX_FOLD": "0"},
-             {"MGX_FOLD_KMAX": "10", "MGX_FUSE_ROWS": "16"}, {"MGX_FUSE_MIN_N": "1024"}, {"MGX_FUSE": "2", "MGX_FUSE_MIN_N": "128"}]
+             {"MGX_FOLD_KMAX": "10", "MGX_FUSE_ROWS": "16"}, {"MGX_FUSE_MIN_N": "1024"}, {"MGX_FUSE": "2", "MGX_FUSE_MIN_N": "128"},
+             {"MGX_ZERO_IN": "0"}, {"MGX_ZERO_IN": "0", "MGX_FOLD": "0"}]
     ref = None
     for kn in knobs:
-        for k in ("MGX_FUSE", "MGX_ROWS", "MGX_FOLD", "MGX_FOLD_KMAX", "MGX_FUSE_ROWS", "MGX_FUSE_MIN_N"):
+        for k in ("MGX_FUSE", "MGX_ROWS", "MGX_FOLD", "MGX_FOLD_KMAX", "MGX_FUSE_ROWS", "MGX_FUSE_MIN_N", "MGX_ZERO_IN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in kn.items():
             monkeypatch.setenv(k, v)

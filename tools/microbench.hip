@@ -234,7 +234,7 @@ void run_level(int level, int iters)
         g.blocks = (int)(((waves + 3) / 4 + 7) / 8 * 8);
         T* src = u; T* dst = tmp;
         float ms = tm.run([&] {
-            hipLaunchKernelGGL((k_jacobi_fused<T, K, 0>), dim3(g.blocks), dim3(kBlock), 0, 0, src, b, dst, N, pitch, 1, N, g.R, g.strips, g.chunks, c0, c1, 0, N, 0, N + 1);
+            hipLaunchKernelGGL((k_jacobi_fused<T, K, 0>), dim3(g.blocks), dim3(kBlock), 0, 0, src, b, dst, N, pitch, 1, N, g.R, g.strips, g.chunks, c0, c1, 0, N, 0, N + 1, 0);
             std::swap(src, dst);
         }, 3, iters);
         char nm[64]; snprintf(nm, sizeof nm, "jacobi fused K=%d R=%d (per sweep)", K, R);
@@ -249,7 +249,7 @@ void run_level(int level, int iters)
         g.blocks = (int)(((waves + 3) / 4 + 7) / 8 * 8);
         T* src = u; T* dst = tmp;
         float ms = tm.run([&] {
-            hipLaunchKernelGGL((k_jacobi_fused<T, K, 1>), dim3(g.blocks), dim3(kBlock), 0, 0, src, b, dst, N, pitch, 1, N, g.R, g.strips, g.chunks, c0, c1, 0, N, 0, N + 1);
+            hipLaunchKernelGGL((k_jacobi_fused<T, K, 1>), dim3(g.blocks), dim3(kBlock), 0, 0, src, b, dst, N, pitch, 1, N, g.R, g.strips, g.chunks, c0, c1, 0, N, 0, N + 1, 0);
             std::swap(src, dst);
         }, 3, iters);
         char nm[64]; snprintf(nm, sizeof nm, "rbgs fused sweeps=%d R=%d (per sweep)", K / 2, R);
