@@ -70,10 +70,19 @@ def run(args, emit=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal mode for a 1-GPU box (RCCL refuses two ranks on one device): backend gloo with
+    # host-staged halos, every rank on device 0.  The default is what the contract asks for:
+    # one rank per GPU, backend nccl (= RCCL over xGMI).
+    backend = os.environ.get("MGX_DIST_BACKEND", "nccl")
+    if os.environ.get("MGX_DIST_SINGLE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     use_pg = world > 1 or bool(os.environ.get("MGX_FORCE_DIST"))
     if use_pg:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     if args.dtype == "mixed":
         raise SystemExit("--dtype mixed is a single-GPU configuration in this round")
@@ -90,7 +99,7 @@ def run(args, emit=None):
     ops = HipSlabOps(dtype)
     coarse = HipCoarseSolver(cut, min(args.coarsest, cut), cfg, dtype)
     mg = DistMultigrid(ops, coarse, L, cut, mu1=args.mu1, mu2=args.mu2, omega=args.omega, smoother=args.smoother,
-                       restrict_mode=cfg["restrict_mode"])
+                       restrict_mode=cfg["restrict_mode"], staged_halo=(backend != "nccl"))
     mg.profile = True
     mg.set_fine("b", _rhs_sine)
     mg.set_fine("u", _hash_uniform)
@@ -117,7 +126,7 @@ def run(args, emit=None):
         mg.residual_norm()
     barrier()
     secs = time.perf_counter() - t0
-    t = torch.tensor([secs], dtype=torch.float64, device="cuda")
+    t = torch.tensor([secs], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if use_pg:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     secs = float(t.item())
@@ -141,8 +150,8 @@ def run(args, emit=None):
             "config": {
                 "workload": f"2D Poisson {1 << L}^2 (n={n} interior), {L - min(args.coarsest, cut) + 1}-level V({args.mu1},{args.mu2}) cycle, "
                             f"{'weighted Jacobi w=%.4f' % args.omega if args.smoother == 'jacobi' else 'red-black Gauss-Seidel'}, "
-                            f"{args.dtype}, row slabs over {world} GPUs on levels {cut + 1}..{L} ({mg.halo}-row deep halos, RCCL "
-                            f"send/recv), levels <= {cut} replicated, exact bottom solve at {(1 << min(args.coarsest, cut)) - 1}^2",
+                            f"{args.dtype}, row slabs over {world} GPUs on levels {cut + 1}..{L} ({mg.halo}-row deep halos, "
+                            f"{'RCCL send/recv' if backend == 'nccl' else backend + ' with host-staged halos (rehearsal)'}), levels <= {cut} replicated, exact bottom solve at {(1 << min(args.coarsest, cut)) - 1}^2",
                 "finest_level": L, "coarsest_level": min(args.coarsest, cut), "cut_level": cut, "mu1": args.mu1,
                 "mu2": args.mu2, "smoother": args.smoother, "step": "one V-cycle + residual norm",
                 "parallelism": f"slab{world}",
