@@ -19,9 +19,9 @@ HIST_TOL = 1e-10       # relative, per cycle (north_star)
 HIST_FLOOR = 1e-13
 
 
-def hist_close(h, ref, rtol=HIST_TOL):
+def hist_close(h, ref, rtol=HIST_TOL, floor_abs=0.0):
     h, ref = np.asarray(h), np.asarray(ref)
-    return len(h) == len(ref) and bool(np.all(np.abs(h - ref) <= rtol * ref + HIST_FLOOR * ref[0]))
+    return len(h) == len(ref) and bool(np.all(np.abs(h - ref) <= rtol * ref + max(HIST_FLOOR * ref[0], floor_abs)))
 
 
 def problem(po, L, rhs):
@@ -234,3 +234,34 @@ def test_tuning_knobs_never_change_a_bit(pkg, po, monkeypatch, smoother):
             _, h_orc = po.Solver(**cfg).solve(b, u0, tol=0.0, max_cycles=2)
             assert hist_close(h, h_orc)
         assert np.array_equal(u, ref), kn
+
+
+def test_seeded_fuzz_of_configurations_against_the_oracle(pkg, po):
+    """40 random configurations (fixed seed): levels 4..10, 0..6 sweeps, both smoothers, f64 and
+    mixed, V and FMG, both restriction weights and bottom modes.  Every history must match the
+    oracle's (1e-10 relative above the rounding floor for f64; 1e-3 for the float inner cycle)."""
+    rng = np.random.default_rng(20261004)
+    for case in range(40):
+        finest = int(rng.integers(6, 11))
+        coarsest = int(rng.integers(max(2, finest - 5), finest + 1))
+        coarsest = min(coarsest, 8)
+        cfg = dict(finest_level=finest, coarsest_level=coarsest,
+                   mu0=int(rng.integers(0, 2)), mu1=int(rng.integers(0, 7)), mu2=int(rng.integers(0, 7)),
+                   omega=float(rng.choice([2.0 / 3.0, 0.8, 0.5])), smoother=int(rng.integers(0, 2)),
+                   dtype=int(rng.choice([1, 1, 2])), schedule=int(rng.integers(0, 2)),
+                   restrict_mode=int(rng.choice([0, 0, 1])), bottom=int(rng.choice([0, 0, 1])))
+        if cfg["mu1"] + cfg["mu2"] == 0:
+            cfg["mu1"] = 1
+        n = (1 << finest) - 1
+        b = po.rhs_sine(finest) if case % 2 else po.rhs_constant(finest)
+        u0 = po.fill_uniform((n, n), 1000 + case) if case % 3 == 0 and cfg["schedule"] == 0 else None
+        st, h, u = run_gpu(pkg, cfg, b, u0, tol=1e-9, max_cycles=6)
+        u_ref, h_ref = po.Solver(**cfg).solve(b, u0, tol=1e-9, max_cycles=6)
+        assert len(h) == len(h_ref), (case, cfg, h, h_ref)
+        rtol = 1e-3 if cfg["dtype"] == 2 else HIST_TOL
+        scale = max(np.max(np.abs(u_ref)), 1e-300)
+        # rounding floor of a double residual: eps * (|b| + 8|u|) per entry, n entries per row and
+        # column in the 2-norm; it is what is left after an exact solve (one-level hierarchies)
+        floor = 32 * np.finfo(np.float64).eps * scale * n
+        assert hist_close(h, h_ref, rtol, floor), (case, cfg, h, h_ref)
+        assert np.max(np.abs(u - u_ref)) <= (1e-7 if cfg["dtype"] == 2 else 1e-10) * scale, (case, cfg)
