@@ -53,7 +53,7 @@ struct EventPair { hipEvent_t a, b; int cls; long long launches; long long sweep
 
 // temporal fusion knobs: levels per pass, chunk height (0 = by grid size), smallest
 // fused grid, levels per pass for the folded kernels
-struct FuseCfg { int kmax; int rows; int min_n; int fold_kmax; };
+struct FuseCfg { int kmax; int rows; int min_n; int fold_kmax; int fold_kmax_big; };
 
 } // namespace
 
@@ -71,7 +71,7 @@ struct mgx_solver {
     double* sum_host = nullptr;     // pinned
     std::string err;
     int rows_per_chunk = 0;         // 0 = auto (MGX_ROWS env overrides)
-    FuseCfg fuse{10, 0, 256, 5};    // temporal fusion knobs (MGX_FUSE, MGX_FUSE_ROWS, MGX_FUSE_MIN_N, MGX_FOLD_KMAX)
+    FuseCfg fuse{10, 0, 256, 5, 5};   // temporal fusion knobs (MGX_FUSE, MGX_FUSE_ROWS, MGX_FUSE_MIN_N, MGX_FOLD_KMAX[_BIG])
     // profiling
     std::vector<EventPair> ev_used, ev_free;
     double prof_ms[MGX_PROF_COUNT] = {0};
@@ -233,6 +233,10 @@ inline FuseCfg fuse_cfg()
     // flat: measured in one process on one MI355X, V(10,10) at 8192^2 fp64 takes 2.63 ms as
     // [5,5] and 2.62 as [10] (244-256 VGPRs, 2 waves/SIMD); [5,5] is better on smaller grids.
     f.fold_kmax = std::max(1, std::min(f.kmax, env_int("MGX_FOLD_KMAX", 5)));
+    // The same for grids with N >= 8192 (separate knob): there the deep variant [10] is
+    // device-dependent - 1.55 vs 1.62 ms for the finest level on one MI355X, 1.87 vs 1.50 ms on
+    // another (VALU-bound passes follow the clock the chip holds; the HBM-bound [5,5] does not).
+    f.fold_kmax_big = std::max(1, std::min(f.kmax, env_int("MGX_FOLD_KMAX_BIG", 5)));
     return f;
 }
 
@@ -546,7 +550,7 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
 // (post = 1) or the residual norm (post = 2) produced by the last pass.
 // Returns false when this level / configuration is not eligible (caller then
 // uses the stand-alone kernels); on success *norm_blocks = partial sums written.
-inline int fold_kmax(const mgx_solver* s) { return s->fuse.fold_kmax; }
+inline int fold_kmax(const mgx_solver* s, int N) { return N >= 8192 ? s->fuse.fold_kmax_big : s->fuse.fold_kmax; }
 
 template <typename T, int SM>
 bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool pre, int post, int* launches,
@@ -555,7 +559,7 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
     constexpr bool rbgs = (SM == 1);
     constexpr int per = rbgs ? 2 : 1;
     int parts[64];
-    const int np = plan_fusion(mu, fold_kmax(s), sizeof(T) == 8, parts, rbgs);
+    const int np = plan_fusion(mu, fold_kmax(s, l.N), sizeof(T) == 8, parts, rbgs);
     const T om = (T)s->cfg.omega;
     const T c0 = (T)(1.0 - (double)om);
     const T c1 = (T)((double)om / 4.0);
@@ -599,7 +603,7 @@ bool fold_eligible(const mgx_solver* s, const Level& l, int mu)
     const int per = rbgs ? 2 : 1;
     if (s->fuse.kmax < per) return false;
     int parts[64];
-    const int np = plan_fusion(mu, fold_kmax(s), l.f64, parts, rbgs);
+    const int np = plan_fusion(mu, fold_kmax(s, l.N), l.f64, parts, rbgs);
     for (int p = 0; p < np; ++p)
         if (!cycle_k_supported(per * parts[p], rbgs)) return false;
     // the norm partials of the folded pass must fit the reduction buffer
@@ -617,7 +621,7 @@ bool zero_in_ok(const mgx_solver* s, int level)
     if (!fold_eligible(s, l, mu)) return false;
     const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
     int parts[64];
-    const int np = plan_fusion(mu, fold_kmax(s), l.f64, parts, rbgs);
+    const int np = plan_fusion(mu, fold_kmax(s, l.N), l.f64, parts, rbgs);
     return !(np >= 2 && !rbgs && parts[0] == 1);      // a leading plain single Jacobi sweep reads its input
 }
 
