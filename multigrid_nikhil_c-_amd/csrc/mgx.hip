@@ -53,7 +53,7 @@ struct EventPair { hipEvent_t a, b; int cls; long long launches; long long sweep
 
 // temporal fusion knobs: levels per pass, chunk height (0 = by grid size), smallest
 // fused grid, levels per pass for the folded kernels
-struct FuseCfg { int kmax; int rows; int min_n; int fold_kmax; int fold_kmax_big; };
+struct FuseCfg { int kmax; int rows; int min_n; int fold_kmax; int fold_kmax_big; int tile_max_n; int tile_k; };
 
 } // namespace
 
@@ -71,7 +71,7 @@ struct mgx_solver {
     double* sum_host = nullptr;     // pinned
     std::string err;
     int rows_per_chunk = 0;         // 0 = auto (MGX_ROWS env overrides)
-    FuseCfg fuse{10, 0, 256, 5, 5};   // temporal fusion knobs (MGX_FUSE, MGX_FUSE_ROWS, MGX_FUSE_MIN_N, MGX_FOLD_KMAX[_BIG])
+    FuseCfg fuse{10, 0, 256, 5, 5, 1024, 10};   // temporal fusion knobs (MGX_FUSE, MGX_FUSE_ROWS, MGX_FUSE_MIN_N, MGX_FOLD_KMAX[_BIG])
     // profiling
     std::vector<EventPair> ev_used, ev_free;
     double prof_ms[MGX_PROF_COUNT] = {0};
@@ -237,6 +237,10 @@ inline FuseCfg fuse_cfg()
     // device-dependent - 1.55 vs 1.62 ms for the finest level on one MI355X, 1.87 vs 1.50 ms on
     // another (VALU-bound passes follow the clock the chip holds; the HBM-bound [5,5] does not).
     f.fold_kmax_big = std::max(1, std::min(f.kmax, env_int("MGX_FOLD_KMAX_BIG", 5)));
+    // Whole levels up to this N (= 2^L) are smoothed by the LDS tile kernel, all sweeps of a
+    // block (up to tile_k levels) per launch; 0 disables it.
+    f.tile_max_n = std::max(0, env_int("MGX_TILE_MAX_N", 1024));
+    f.tile_k = std::max(2, std::min(10, env_int("MGX_TILE_K", 10)));
     return f;
 }
 
@@ -380,6 +384,56 @@ int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, i
 inline bool cycle_k_supported(int K, bool rbgs)
 {
     return rbgs ? (K == 2 || K == 4 || K == 6 || K == 8 || K == 10) : ((K >= 1 && K <= 8 && K != 7) || K == 10);
+}
+
+// ---- small levels: every sweep of a block in one launch on register tiles (k_tile_smooth) ----
+template <typename T, int SM, int PRE, int POST>
+int launch_tile(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N, long pitch, T c0, T c1, int levels,
+                hipStream_t st)
+{
+    const int He = levels + tile_extra<POST>();
+    const int TH = kTileSY - 2 * He, TW = kTileSX - 2 * He;
+    if (TH < 8 || TW < 8) return -1;
+    const int tiles_y = (N - 1 + TH - 1) / TH, tiles_x = (N - 1 + TW - 1) / TW;
+    const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
+    hipLaunchKernelGGL((k_tile_smooth<T, SM, PRE, POST>), dim3(tiles_y * tiles_x), dim3(kBlock), 0, st, vin, b, vout,
+                       (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
+                       levels, c0, c1, tiles_x, fa.zero_in);
+    return tiles_y * tiles_x;
+}
+
+// mu sweeps of a whole level, a <-> b2 ping-pong (*flips launches made); pre / post as in
+// smooth_folded_t.  Returns the number of norm partials (post == 2), < 0 on a launch error.
+template <typename T, int SM>
+int smooth_tiled(T* a, const T* rhs, T* b2, int N, long pitch, int mu, double omega, int tile_k, FoldArgs fa,
+                 bool pre, int post, bool zero_in, hipStream_t st, int* flips)
+{
+    constexpr int per = (SM == 1) ? 2 : 1;
+    const T om = (T)omega;
+    const T c0 = (T)(1.0 - (double)om);
+    const T c1 = (T)((double)om / 4.0);
+    const int smax = std::max(1, tile_k / per);            // sweeps per launch
+    const int np = (mu + smax - 1) / smax;
+    T* src = a; T* dst = b2;
+    int blocks = 0;
+    for (int p = 0; p < np; ++p) {
+        const int sw = mu / np + (p < mu % np ? 1 : 0);
+        const bool P = pre && p == 0;
+        const int Q = (p == np - 1) ? post : 0;
+        fa.zero_in = (p == 0 && zero_in) ? 1 : 0;
+        int rc;
+        if (P && Q == 2) rc = launch_tile<T, SM, 1, 2>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
+        else if (P && Q == 1) rc = launch_tile<T, SM, 1, 1>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
+        else if (P) rc = launch_tile<T, SM, 1, 0>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
+        else if (Q == 1) rc = launch_tile<T, SM, 0, 1>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
+        else if (Q == 2) rc = launch_tile<T, SM, 0, 2>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
+        else rc = launch_tile<T, SM, 0, 0>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
+        if (rc < 0) return -1;
+        if (Q == 2) blocks = rc;
+        std::swap(src, dst);
+    }
+    *flips = np;
+    return blocks;
 }
 
 template <typename T>
@@ -535,10 +589,23 @@ int copy_out(mgx_solver* s, Level& l, const void* src_grid, void* dst, size_t co
 }
 
 // ---- operators on the working hierarchy -----------------------------------------------
+inline bool tile_level(const mgx_solver* s, const Level& l) { return s->fuse.tile_max_n > 0 && l.N <= s->fuse.tile_max_n; }
+
 template <typename T>
 void smooth_t(mgx_solver* s, Level& l, int mu)
 {
     int parity = 0, launches = 0;
+    if (tile_level(s, l)) {
+        FoldArgs fa;
+        const int rc = s->cfg.smoother == MGX_SMOOTHER_RBGS
+            ? smooth_tiled<T, 1>((T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, mu, s->cfg.omega, s->fuse.tile_k, fa, false, 0, false, s->stream, &launches)
+            : smooth_tiled<T, 0>((T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, mu, s->cfg.omega, s->fuse.tile_k, fa, false, 0, false, s->stream, &launches);
+        if (rc >= 0) {
+            s->last_smooth_launches = launches;
+            if (launches & 1) std::swap(l.u, l.tmp);
+            return;
+        }
+    }
     (void)smooth_block<T>(s->cfg.smoother, (T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, l.rows, 1, l.N, mu,
                           s->cfg.omega, false, 1, l.N, 0, s->rows_per_chunk, s->fuse, s->stream, &parity, &launches);
     s->last_smooth_launches = launches;
@@ -558,11 +625,6 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
 {
     constexpr bool rbgs = (SM == 1);
     constexpr int per = rbgs ? 2 : 1;
-    int parts[64];
-    const int np = plan_fusion(mu, fold_kmax(s, l.N), sizeof(T) == 8, parts, rbgs);
-    const T om = (T)s->cfg.omega;
-    const T c0 = (T)(1.0 - (double)om);
-    const T c1 = (T)((double)om / 4.0);
     FoldArgs fa;
     fa.restrict_mode = s->cfg.restrict_mode;
     fa.partial = s->partial;
@@ -571,6 +633,21 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
         // PS:613: zero the coarse guess here unless its first pre-smoothing pass synthesises it
         fa.coarse_zero = (post == 1 && s->zero_in_level == coarse->L) ? nullptr : coarse->u;
     }
+    if (tile_level(s, l)) {
+        int flips = 0;
+        const int nb = smooth_tiled<T, SM>((T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, mu, s->cfg.omega,
+                                           s->fuse.tile_k, fa, pre, post, zero_in, s->stream, &flips);
+        if (nb < 0) return false;
+        if (flips & 1) std::swap(l.u, l.tmp);
+        if (post == 2) *norm_blocks = nb;
+        *launches = flips;
+        return true;
+    }
+    int parts[64];
+    const int np = plan_fusion(mu, fold_kmax(s, l.N), sizeof(T) == 8, parts, rbgs);
+    const T om = (T)s->cfg.omega;
+    const T c0 = (T)(1.0 - (double)om);
+    const T c1 = (T)((double)om / 4.0);
     T* src = (T*)l.u; T* dst = (T*)l.tmp;
     const T* b = (const T*)l.b;
     for (int p = 0; p < np; ++p) {
@@ -598,7 +675,9 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
 // pre-check made before any launch (so a `false` never leaves a half-done block)
 bool fold_eligible(const mgx_solver* s, const Level& l, int mu)
 {
-    if (!s->fold || mu < 1 || mu > 64 || l.N < s->fuse.min_n) return false;
+    if (!s->fold || mu < 1 || mu > 64) return false;
+    if (tile_level(s, l)) return true;
+    if (l.N < s->fuse.min_n) return false;
     const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
     const int per = rbgs ? 2 : 1;
     if (s->fuse.kmax < per) return false;
@@ -619,6 +698,7 @@ bool zero_in_ok(const mgx_solver* s, int level)
     const Level& l = s->lv[level];
     const int mu = s->cfg.mu1;
     if (!fold_eligible(s, l, mu)) return false;
+    if (tile_level(s, l)) return true;
     const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
     int parts[64];
     const int np = plan_fusion(mu, fold_kmax(s, l.N), l.f64, parts, rbgs);
@@ -919,6 +999,7 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
             cap = std::max(cap, sumsq_blocks<double>(N, N, rpc));
             cap = std::max(cap, sumsq_blocks<float>(N, N, rpc));
         }
+        if (N <= s->fuse.tile_max_n) cap = std::max(cap, (long)((N + 31) / 32) * ((N + 39) / 40));   // tiles >= 32 x 40
         s->partial_cap = cap + 8;
         if (hipMalloc(&s->partial, s->partial_cap * sizeof(double)) != hipSuccess ||
             hipMalloc(&s->sum_dev, sizeof(double)) != hipSuccess ||

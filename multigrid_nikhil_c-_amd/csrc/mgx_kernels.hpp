@@ -1019,6 +1019,185 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     }
 }
 
+// =============================================================================
+// k_tile_smooth: a whole smoothing block on a SMALL level in one launch.
+//
+// Levels up to ~1024^2 are latency-bound for the marching kernels: a wave walks
+// its R + 2K rows one after the other and there are fewer waves than SIMDs.
+// Here a workgroup takes a tile and performs ALL `levels` smoother levels on it
+// in lockstep, with the tile in REGISTERS and LDS carrying the halo rows between
+// waves:
+//   * the workgroup's array is 56 rows x 64 columns of nodes = the output tile
+//     plus a halo of He = levels (+2 / +1 for a folded restriction / norm) nodes
+//     on every side; halo nodes are recomputed redundantly (level j is valid on
+//     the array minus j nodes per side), so tiles never talk to each other;
+//   * lane = column, wave w owns the 14-row band [14 w, 14 w + 14): u and b of
+//     the band stay in 2 x 14 registers per lane for the whole kernel;
+//   * x-neighbours come from the adjacent lanes by DPP, the y-neighbours of the
+//     band's first / last row from the adjacent wave through a double-buffered
+//     LDS halo (one barrier per level).
+// Same arithmetic in the same order as every other kernel: bit-identical.
+//   SM 0: weighted Jacobi.  SM 1: red-black Gauss-Seidel, level j updates colour
+//   (j-1)&1 in place (its neighbours all have the other colour).
+//   PRE 1: v + P e while loading (PS:620-624).  POST 1: residual of the result,
+//   restricted into the coarse right-hand side, coarse guess zeroed (PS:604-613).
+//   POST 2: sum (b - A v)^2 -> partial[block].
+// Whole grids only (rows/cols 0..N exist, coarse node I on fine node 2I).
+// =============================================================================
+constexpr int kTileBand = 14;                       // array rows per wave
+constexpr int kTileSY = kWavesPerBlock * kTileBand; // 56 array rows per workgroup
+constexpr int kTileSX = kWave;                      // 64 array columns
+
+template <int POST> constexpr int tile_extra() { return POST == 1 ? 2 : (POST == 2 ? 1 : 0); }
+
+template <typename T, int SM, int PRE, int POST>
+__global__ void __launch_bounds__(kBlock)
+k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
+              const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
+              double* __restrict__ partial, int N, long pitch, long cpitch, int levels, T c0, T c1,
+              int tiles_x, int zero_in)
+{
+    constexpr int RW = kTileBand;
+    __shared__ T edge[2][kWavesPerBlock][2][kWave];     // [buffer][wave][first / last row][lane]
+    __shared__ double wsum[kWavesPerBlock];
+    const int He = levels + tile_extra<POST>();
+    const int TH = kTileSY - 2 * He, TW = kTileSX - 2 * He;    // output tile
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = wv * RW;                         // array row of this wave's register row 0
+    const int gy0 = 1 + ty * TH - He + y0;          // its global node row
+    const int gx = 1 + tx * TW - He + lane;         // this lane's global node column
+    const bool colunk = gx > 0 && gx < N;
+    const int NC = N / 2;
+
+    // ---- load the band (with the correction, PRE) ----------------------------------------
+    T u[RW], b[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int gy = gy0 + i;
+        const bool unk = colunk && gy > 0 && gy < N;
+        T v = (T)0, bb = (T)0;
+        if (unk) {
+            const long at = (long)gy * pitch + gx;
+            if (!zero_in) v = vin[at];
+            bb = rhs[at];
+            if (PRE) {
+                const T* e = coarse_e + (long)(gy >> 1) * cpitch + (gx >> 1);
+                T add;
+                if ((gy & 1) == 0) add = (gx & 1) == 0 ? e[0] : (T)0.5 * (e[0] + e[1]);
+                else if ((gx & 1) == 0) add = (T)0.5 * (e[0] + e[cpitch]);
+                else add = (T)0.25 * (((e[0] + e[cpitch]) + e[1]) + e[cpitch + 1]);
+                v = v + add;
+            }
+        }
+        u[i] = v;
+        b[i] = bb;
+    }
+
+    // ---- the smoother levels, in lockstep over the workgroup ---------------------------
+    int buf = 0;
+    auto halo_rows = [&](const T (&a)[RW], T& up, T& dn) {
+        edge[buf][wv][0][lane] = a[0];
+        edge[buf][wv][1][lane] = a[RW - 1];
+        __syncthreads();
+        up = wv > 0 ? edge[buf][wv - 1][1][lane] : (T)0;
+        dn = wv < kWavesPerBlock - 1 ? edge[buf][wv + 1][0][lane] : (T)0;
+        buf ^= 1;       // the next exchange writes the other buffer; its barrier orders the re-use of this one
+    };
+    for (int j = 1; j <= levels; ++j) {
+        T up, dn;
+        halo_rows(u, up, dn);
+        const bool colact = colunk && lane >= j && lane < kTileSX - j;
+        T prev = up;                                // old value of the row above
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const T cur = u[i];
+            const T below = (i == RW - 1) ? dn : u[i + 1];
+            const int y = y0 + i, gy = gy0 + i;
+            if (y >= j && y < kTileSY - j && gy > 0 && gy < N) {        // wave-uniform
+                const T l = from_left(cur), r = from_right(cur);
+                if (SM == 0) {
+                    const T o = (c0 * cur + c1 * b[i]) + c1 * nbr(prev, l, r, below);
+                    u[i] = colact ? o : cur;
+                } else {
+                    const T o = (T)0.25 * (b[i] + nbr(prev, l, r, below));
+                    u[i] = (colact && ((gy + gx) & 1) == ((j - 1) & 1)) ? o : cur;
+                }
+            }
+            prev = cur;
+        }
+    }
+    // u is the result on array rows / columns [levels, 56 - levels) x [levels, 64 - levels)
+
+    // ---- store the tile -------------------------------------------------------------------------
+    const bool colout = lane >= He && lane < He + TW && gx < N;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int y = y0 + i, gy = gy0 + i;
+        if (y >= He && y < He + TH && gy < N && colout) vout[(long)gy * pitch + gx] = u[i];
+    }
+
+    if (POST != 0) {
+        // residual of the result: r = b - A u on the tile (+- 1 node for the restriction)
+        T up, dn;
+        halo_rows(u, up, dn);
+        T res[RW];
+        double acc = 0.0;
+        T prev = up;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const T cur = u[i];
+            const T below = (i == RW - 1) ? dn : u[i + 1];
+            const int y = y0 + i, gy = gy0 + i;
+            const T l = from_left(cur), r = from_right(cur);
+            T rr = (T)0;
+            if (colunk && gy > 0 && gy < N) rr = b[i] - (-nbr(prev, l, r, below) + (T)4 * cur);
+            res[i] = rr;
+            if (POST == 2 && y >= He && y < He + TH && colout) acc += (double)rr * (double)rr;
+            prev = cur;
+        }
+        if (POST == 2) {
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
+            if (lane == 0) wsum[wv] = acc;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double sum = 0.0;
+                for (int w2 = 0; w2 < kWavesPerBlock; ++w2) sum += wsum[w2];
+                partial[blockIdx.x] = sum;
+            }
+        }
+        if (POST == 1) {
+            T rup, rdn;
+            halo_rows(res, rup, rdn);
+            const int J = gx >> 1;
+            const bool cst = colout && (gx & 1) == 0 && J >= 1 && J < NC;
+#pragma unroll
+            for (int i = 0; i < RW; ++i) {
+                const T c = res[i];
+                const T n = (i == 0) ? rup : res[i - 1];
+                const T s2 = (i == RW - 1) ? rdn : res[i + 1];
+                const int y = y0 + i, gy = gy0 + i;
+                if (y >= He && y < He + TH && (gy & 1) == 0 && gy < N) {       // wave-uniform: a coarse row
+                    // PS:539-542 order: ((nw+ne)+sw)+se + 2*(((w+e)+n)+s) + 4*c
+                    T corners = from_left(n) + from_right(n);
+                    corners = corners + from_left(s2);
+                    corners = corners + from_right(s2);
+                    T edges = from_left(c) + from_right(c);
+                    edges = edges + n;
+                    edges = edges + s2;
+                    const T o = wgt * ((corners + (T)2 * edges) + (T)4 * c);
+                    if (cst) {
+                        const long at = (long)(gy >> 1) * cpitch + J;
+                        coarse_b[at] = o;
+                        if (coarse_zero) coarse_zero[at] = (T)0;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // mixed precision (config 5): u64 += scale * (double) e32, rows [row_lo,row_hi)
 __global__ void __launch_bounds__(kBlock)
 k_axpy_f32_to_f64(double* __restrict__ u, const float* __restrict__ e, double scale, int N, long pitch, long epitch,

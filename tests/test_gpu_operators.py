@@ -34,14 +34,26 @@ def exact(a, b):
     return np.array_equal(a, b)
 
 
-@pytest.fixture(scope="module")
-def mgs(pkg):
-    """one handle per (dtype, smoother) spanning levels 2..10"""
+@pytest.fixture(scope="module", params=["tiles", "marching"])
+def mgs(pkg, request):
+    """one handle per (dtype, smoother) spanning levels 2..10; once with the LDS tile kernel
+    on the small levels (the default), once with the marching kernels everywhere"""
+    old = os.environ.get("MGX_TILE_MAX_N")
+    if request.param == "marching":
+        os.environ["MGX_TILE_MAX_N"] = "0"
+    else:
+        os.environ.pop("MGX_TILE_MAX_N", None)
     hs = {}
-    for name, (dt, code, _) in DT.items():
-        for sm in (0, 1):
-            hs[(name, sm)] = pkg.Multigrid(finest_level=10, coarsest_level=2, dtype=code, smoother=sm,
-                                           bottom=pkg.BOTTOM_SMOOTH)
+    try:
+        for name, (dt, code, _) in DT.items():
+            for sm in (0, 1):
+                hs[(name, sm)] = pkg.Multigrid(finest_level=10, coarsest_level=2, dtype=code, smoother=sm,
+                                               bottom=pkg.BOTTOM_SMOOTH)
+    finally:
+        if old is None:
+            os.environ.pop("MGX_TILE_MAX_N", None)
+        else:
+            os.environ["MGX_TILE_MAX_N"] = old
     yield hs
     for h in hs.values():
         h.close()
@@ -195,6 +207,7 @@ def test_fused_sweeps_are_bit_identical_to_single_sweeps(pkg, po, name, kmax, mo
     dt, code, _ = DT[name]
     monkeypatch.setenv("MGX_FUSE", str(kmax))
     monkeypatch.setenv("MGX_FUSE_ROWS", "16")
+    monkeypatch.setenv("MGX_TILE_MAX_N", "0")          # the marching kernels on every level
     rng = np.random.default_rng(700 + kmax)
     with pkg.Multigrid(finest_level=11, coarsest_level=8, dtype=code, bottom=pkg.BOTTOM_SMOOTH) as mg:
         for level in (8, 9, 10, 11):
@@ -211,3 +224,31 @@ def test_fused_sweeps_are_bit_identical_to_single_sweeps(pkg, po, name, kmax, mo
         v[0, :] = v[-1, :] = v[:, 0] = v[:, -1] = 1
         f[0, 0] = f[-1, -1] = 3
         assert exact(mg.jacobirelaxation(10, v, f, kmax), po.jacobi(v, f, kmax))
+
+
+@pytest.mark.parametrize("name", ["f64", "f32"])
+@pytest.mark.parametrize("tile_k", [10, 4, 3])
+def test_lds_tile_smoother_is_bit_identical(pkg, po, name, tile_k, monkeypatch):
+    """k_tile_smooth (all sweeps of a block on 32 x 32 LDS tiles with halos, tile_k levels per
+    launch) against the oracle: every level it serves, both smoothers, sweep counts that need
+    one, two and three launches, and data concentrated next to the Dirichlet ring"""
+    dt, code, _ = DT[name]
+    monkeypatch.setenv("MGX_TILE_K", str(tile_k))
+    monkeypatch.delenv("MGX_TILE_MAX_N", raising=False)
+    rng = np.random.default_rng(900 + tile_k)
+    for sm, orc in ((0, po.jacobi), (1, po.rbgs)):
+        with pkg.Multigrid(finest_level=10, coarsest_level=2, dtype=code, smoother=sm, bottom=pkg.BOTTOM_SMOOTH) as mg:
+            for level in (2, 3, 4, 5, 6, 7, 9, 10):
+                n = (1 << level) - 1
+                v = rng.uniform(-1, 1, (n, n)).astype(dt)
+                f = rng.uniform(-1, 1, (n, n)).astype(dt)
+                for mu in ((1, 2, 5, 10, 11, 23) if sm == 0 else (1, 2, 5, 6, 11)):
+                    if level >= 9 and mu > 11:
+                        continue
+                    assert exact(mg.jacobirelaxation(level, v, f, mu), orc(v, f, mu)), (name, sm, tile_k, level, mu)
+            n = 1023
+            v = np.zeros((n, n), dtype=dt); f = np.zeros((n, n), dtype=dt)
+            v[0, :] = v[-1, :] = v[:, 0] = v[:, -1] = 1
+            v[31, :] = v[32, :] = v[:, 31] = v[:, 32] = -2          # tile seams
+            f[0, 0] = f[-1, -1] = 3
+            assert exact(mg.jacobirelaxation(10, v, f, 7), orc(v, f, 7))

@@ -192,11 +192,17 @@ def test_config1_parameters_at_8192_jacobi_v1010(pkg):
     assert st.fine_updates == 20.0 * st.cycles * n * n
 
 
+@pytest.mark.parametrize("tiles", ["tiles", "marching"])
 @pytest.mark.parametrize("dtype", [1, 0])
 @pytest.mark.parametrize("mu1,mu2", [(10, 10), (2, 1), (1, 1), (5, 3), (3, 0), (6, 8)])
-def test_folded_cycle_passes_are_bit_identical(pkg, po, monkeypatch, dtype, mu1, mu2):
-    """k_jacobi_cycle (correction on load, residual+restriction and ||r||^2 appended to the
-    smoother passes) must give the bits of the stand-alone kernels, and both must match the oracle"""
+def test_folded_cycle_passes_are_bit_identical(pkg, po, monkeypatch, dtype, mu1, mu2, tiles):
+    """k_jacobi_cycle / k_tile_smooth (correction on load, residual+restriction and ||r||^2
+    appended to the smoother passes) must give the bits of the stand-alone kernels, and both
+    must match the oracle.  Level 11 always marches; 10..8 use LDS tiles or march."""
+    if tiles == "marching":
+        monkeypatch.setenv("MGX_TILE_MAX_N", "0")
+    else:
+        monkeypatch.delenv("MGX_TILE_MAX_N", raising=False)
     cfg = dict(finest_level=11, coarsest_level=8, mu1=mu1, mu2=mu2, schedule=0, dtype=dtype)
     b = po.rhs_sine(11)
     u0 = po.fill_uniform(b.shape, 99)
@@ -219,12 +225,16 @@ def test_tuning_knobs_never_change_a_bit(pkg, po, monkeypatch, smoother):
     cfg = dict(finest_level=10, coarsest_level=7, mu1=4, mu2=3, schedule=0, smoother=smoother)
     b = po.rhs_sine(10)
     u0 = po.fill_uniform(b.shape, 5)
-    knobs = [{}, {"MGX_FUSE": "1"}, {"MGX_FUSE": "1", "MGX_ROWS": "8"}, {"MGX_FOLD": "0"},
+    march = [{}, {"MGX_FUSE": "1"}, {"MGX_FUSE": "1", "MGX_ROWS": "8"}, {"MGX_FOLD": "0"},
              {"MGX_FOLD_KMAX": "10", "MGX_FUSE_ROWS": "16"}, {"MGX_FUSE_MIN_N": "1024"}, {"MGX_FUSE": "2", "MGX_FUSE_MIN_N": "128"},
              {"MGX_ZERO_IN": "0"}, {"MGX_ZERO_IN": "0", "MGX_FOLD": "0"}]
+    knobs = [{}] + [dict(kn, MGX_TILE_MAX_N="0") for kn in march]
+    knobs += [{"MGX_TILE_K": "2"}, {"MGX_TILE_K": "5", "MGX_FOLD": "0"}, {"MGX_TILE_MAX_N": "256"},
+              {"MGX_ZERO_IN": "0"}, {"MGX_TILE_MAX_N": "512", "MGX_TILE_K": "3", "MGX_ZERO_IN": "0"}]
     ref = None
     for kn in knobs:
-        for k in ("MGX_FUSE", "MGX_ROWS", "MGX_FOLD", "MGX_FOLD_KMAX", "MGX_FUSE_ROWS", "MGX_FUSE_MIN_N", "MGX_ZERO_IN"):
+        for k in ("MGX_FUSE", "MGX_ROWS", "MGX_FOLD", "MGX_FOLD_KMAX", "MGX_FUSE_ROWS", "MGX_FUSE_MIN_N", "MGX_ZERO_IN",
+                  "MGX_TILE_MAX_N", "MGX_TILE_K"):
             monkeypatch.delenv(k, raising=False)
         for k, v in kn.items():
             monkeypatch.setenv(k, v)
@@ -236,7 +246,7 @@ def test_tuning_knobs_never_change_a_bit(pkg, po, monkeypatch, smoother):
         assert np.array_equal(u, ref), kn
 
 
-def test_seeded_fuzz_of_configurations_against_the_oracle(pkg, po):
+def test_seeded_fuzz_of_configurations_against_the_oracle(pkg, po, monkeypatch):
     """40 random configurations (fixed seed): levels 4..10, 0..6 sweeps, both smoothers, f64 and
     mixed, V and FMG, both restriction weights and bottom modes.  Every history must match the
     oracle's (1e-10 relative above the rounding floor for f64; 1e-3 for the float inner cycle)."""
@@ -255,6 +265,11 @@ def test_seeded_fuzz_of_configurations_against_the_oracle(pkg, po):
         n = (1 << finest) - 1
         b = po.rhs_sine(finest) if case % 2 else po.rhs_constant(finest)
         u0 = po.fill_uniform((n, n), 1000 + case) if case % 3 == 0 and cfg["schedule"] == 0 else None
+        # LDS tiles on every level (the default) or marching kernels, alternating in pairs
+        if (case // 2) % 2:
+            monkeypatch.setenv("MGX_TILE_MAX_N", "0")
+        else:
+            monkeypatch.delenv("MGX_TILE_MAX_N", raising=False)
         st, h, u = run_gpu(pkg, cfg, b, u0, tol=1e-9, max_cycles=6)
         u_ref, h_ref = po.Solver(**cfg).solve(b, u0, tol=1e-9, max_cycles=6)
         assert len(h) == len(h_ref), (case, cfg, h, h_ref)
