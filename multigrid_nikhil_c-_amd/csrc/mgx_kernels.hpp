@@ -1071,28 +1071,36 @@ k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restric
     const bool colunk = gx > 0 && gx < N;
     const int NC = N / 2;
 
-    // ---- load the band (with the correction, PRE) ----------------------------------------
+    // ---- load the band (with the correction, PRE): straight-line, every load in flight at once ----
     T u[RW], b[RW];
+    unsigned rowmask = 0;                           // bit i: register row i is a row of unknowns
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int gy = gy0 + i;
+        if (gy > 0 && gy < N) rowmask |= 1u << i;
         const bool unk = colunk && gy > 0 && gy < N;
-        T v = (T)0, bb = (T)0;
-        if (unk) {
-            const long at = (long)gy * pitch + gx;
-            if (!zero_in) v = vin[at];
-            bb = rhs[at];
-            if (PRE) {
-                const T* e = coarse_e + (long)(gy >> 1) * cpitch + (gx >> 1);
-                T add;
-                if ((gy & 1) == 0) add = (gx & 1) == 0 ? e[0] : (T)0.5 * (e[0] + e[1]);
-                else if ((gx & 1) == 0) add = (T)0.5 * (e[0] + e[cpitch]);
-                else add = (T)0.25 * (((e[0] + e[cpitch]) + e[1]) + e[cpitch + 1]);
-                v = v + add;
-            }
+        const long at = (long)gy * pitch + gx;
+        u[i] = (unk && !zero_in) ? vin[at] : (T)0;
+        b[i] = unk ? rhs[at] : (T)0;
+    }
+    if (PRE) {
+        const bool codd = (gx & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int gy = gy0 + i;
+            const bool unk = colunk && gy > 0 && gy < N;
+            const bool rodd = (gy & 1) != 0;                               // wave-uniform
+            // the four coarse nodes around (gy, gx); all inside the coarse grid when (gy, gx) is an unknown
+            const T* e = coarse_e + (long)(gy >> 1) * cpitch + (gx >> 1);
+            const T a00 = unk ? e[0] : (T)0;
+            const T a01 = (unk && codd) ? e[1] : (T)0;
+            const T a10 = (unk && rodd) ? e[cpitch] : (T)0;
+            const T a11 = (unk && rodd && codd) ? e[cpitch + 1] : (T)0;
+            const T ev = codd ? (T)0.5 * (a00 + a01) : a00;                          // even row
+            const T od = codd ? (T)0.25 * (((a00 + a10) + a01) + a11) : (T)0.5 * (a00 + a10);
+            const T add = rodd ? od : ev;
+            u[i] = unk ? u[i] + add : u[i];
         }
-        u[i] = v;
-        b[i] = bb;
     }
 
     // ---- the smoother levels, in lockstep over the workgroup ---------------------------
@@ -1109,21 +1117,24 @@ k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restric
         T up, dn;
         halo_rows(u, up, dn);
         const bool colact = colunk && lane >= j && lane < kTileSX - j;
+        // rows of this band inside level j's region: i in [j - y0, 56 - j - y0)
+        const int ilo = max(j - y0, 0), ihi = min(kTileSY - j - y0, RW);
+        const unsigned act = ihi > ilo ? (rowmask & (((1u << (ihi - ilo)) - 1u) << ilo)) : 0u;
+        // straight-line over the 14 rows (inactive rows are computed and dropped): the rows are
+        // independent, so their dependent add chains interleave
         T prev = up;                                // old value of the row above
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             const T cur = u[i];
             const T below = (i == RW - 1) ? dn : u[i + 1];
-            const int y = y0 + i, gy = gy0 + i;
-            if (y >= j && y < kTileSY - j && gy > 0 && gy < N) {        // wave-uniform
-                const T l = from_left(cur), r = from_right(cur);
-                if (SM == 0) {
-                    const T o = (c0 * cur + c1 * b[i]) + c1 * nbr(prev, l, r, below);
-                    u[i] = colact ? o : cur;
-                } else {
-                    const T o = (T)0.25 * (b[i] + nbr(prev, l, r, below));
-                    u[i] = (colact && ((gy + gx) & 1) == ((j - 1) & 1)) ? o : cur;
-                }
+            const T l = from_left(cur), r = from_right(cur);
+            const bool rowact = (act >> i) & 1u;                                // wave-uniform
+            if (SM == 0) {
+                const T o = (c0 * cur + c1 * b[i]) + c1 * nbr(prev, l, r, below);
+                u[i] = (colact && rowact) ? o : cur;
+            } else {
+                const T o = (T)0.25 * (b[i] + nbr(prev, l, r, below));
+                u[i] = (colact && rowact && ((gy0 + i + gx) & 1) == ((j - 1) & 1)) ? o : cur;
             }
             prev = cur;
         }
@@ -1178,20 +1189,18 @@ k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restric
                 const T n = (i == 0) ? rup : res[i - 1];
                 const T s2 = (i == RW - 1) ? rdn : res[i + 1];
                 const int y = y0 + i, gy = gy0 + i;
-                if (y >= He && y < He + TH && (gy & 1) == 0 && gy < N) {       // wave-uniform: a coarse row
-                    // PS:539-542 order: ((nw+ne)+sw)+se + 2*(((w+e)+n)+s) + 4*c
-                    T corners = from_left(n) + from_right(n);
-                    corners = corners + from_left(s2);
-                    corners = corners + from_right(s2);
-                    T edges = from_left(c) + from_right(c);
-                    edges = edges + n;
-                    edges = edges + s2;
-                    const T o = wgt * ((corners + (T)2 * edges) + (T)4 * c);
-                    if (cst) {
-                        const long at = (long)(gy >> 1) * cpitch + J;
-                        coarse_b[at] = o;
-                        if (coarse_zero) coarse_zero[at] = (T)0;
-                    }
+                // PS:539-542 order: ((nw+ne)+sw)+se + 2*(((w+e)+n)+s) + 4*c
+                T corners = from_left(n) + from_right(n);
+                corners = corners + from_left(s2);
+                corners = corners + from_right(s2);
+                T edges = from_left(c) + from_right(c);
+                edges = edges + n;
+                edges = edges + s2;
+                const T o = wgt * ((corners + (T)2 * edges) + (T)4 * c);
+                if (cst && y >= He && y < He + TH && (gy & 1) == 0 && gy < N) {     // a coarse row of this tile
+                    const long at = (long)(gy >> 1) * cpitch + J;
+                    coarse_b[at] = o;
+                    if (coarse_zero) coarse_zero[at] = (T)0;
                 }
             }
         }
