@@ -98,3 +98,21 @@ def test_two_distributed_levels_and_replicated_coarse(po):
     h = np.array(got["hist"])
     assert np.all(np.abs(h - h_ref) <= 1e-10 * h_ref + 1e-13 * h_ref[0])
     assert got["exch0"] <= (len(h) - 1) * (1 + 2 * 2) + 2, got["exch0"]
+
+
+def test_eight_ranks_three_distributed_levels(po):
+    """the round-end layout in miniature: 8 ranks, three slab levels above a replicated cut
+    level (bench.py --gpus 8 at 16384^2 distributes levels 14..12 and replicates <= 11)"""
+    cfg = dict(BASE, finest=10, cut=7, coarsest=5, mu1=2, mu2=2, max_cycles=3)
+    got = _run(8, cfg)
+    u_ref, h_ref = _reference(po, cfg)
+    h = np.array(got["hist"])
+    assert len(h) == len(h_ref)
+    assert np.all(np.abs(h - h_ref) <= 1e-10 * h_ref + 1e-13 * h_ref[0]), (h, h_ref)
+    rows = 0
+    for r in range(8):
+        lo, hi, own = got[f"rows{r}"]
+        rows += hi - lo
+        assert np.max(np.abs(own - u_ref[lo - 1:hi - 1])) <= 1e-12 * np.max(np.abs(u_ref))
+    assert rows == (1 << 10) - 1                       # the slabs tile the unknown rows exactly
+    assert got["exch0"] <= (len(h) - 1) * (1 + 2 * 2) + 2, got["exch0"]
