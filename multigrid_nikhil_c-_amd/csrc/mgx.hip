@@ -53,7 +53,7 @@ struct EventPair { hipEvent_t a, b; int cls; long long launches; long long sweep
 
 // temporal fusion knobs: levels per pass, chunk height (0 = by grid size), smallest
 // fused grid, levels per pass for the folded kernels
-struct FuseCfg { int kmax; int rows; int min_n; int fold_kmax; int fold_kmax_big; int tile_max_n; int tile_k; };
+struct FuseCfg { int kmax; int rows; int min_n; int fold_kmax; int fold_kmax_big; int tile_max_n; int tile_k; int fold_kmax_nopost; };
 
 } // namespace
 
@@ -71,7 +71,7 @@ struct mgx_solver {
     double* sum_host = nullptr;     // pinned
     std::string err;
     int rows_per_chunk = 0;         // 0 = auto (MGX_ROWS env overrides)
-    FuseCfg fuse{10, 0, 256, 5, 5, 1024, 10};   // temporal fusion knobs (MGX_FUSE, MGX_FUSE_ROWS, MGX_FUSE_MIN_N, MGX_FOLD_KMAX[_BIG])
+    FuseCfg fuse{10, 0, 256, 5, 5, 1024, 10, 5};   // temporal fusion knobs (MGX_FUSE, MGX_FUSE_ROWS, MGX_FUSE_MIN_N, MGX_FOLD_KMAX[_BIG])
     // profiling
     std::vector<EventPair> ev_used, ev_free;
     double prof_ms[MGX_PROF_COUNT] = {0};
@@ -241,6 +241,9 @@ inline FuseCfg fuse_cfg()
     // block (up to tile_k levels) per launch; 0 disables it.
     f.tile_max_n = std::max(0, env_int("MGX_TILE_MAX_N", 1024));
     f.tile_k = std::max(2, std::min(10, env_int("MGX_TILE_K", 10)));
+    // levels per folded pass for blocks that end WITHOUT a residual stage (post-smoothing below
+    // the finest level): those passes keep c1 * b in their window and are cheaper per level
+    f.fold_kmax_nopost = std::max(1, std::min(f.kmax, env_int("MGX_FOLD_KMAX_NOPOST", f.fold_kmax)));
     return f;
 }
 
@@ -248,8 +251,11 @@ inline FuseCfg fuse_cfg()
 // measured on MI355X at 8192^2 (tools/microbench, profiles/r01_fused_microbench.md).
 // Index = sweeps per launch; 0 = not instantiated.  Jacobi: K = 5 is poor in
 // float because it needs a second halo lane per side for one extra column.
-constexpr double kFuseRate64[11] = {0, 1.00, 1.80, 2.45, 3.16, 3.81, 4.72, 0, 4.98, 0, 5.55};
-constexpr double kFuseRate32[11] = {0, 1.00, 1.66, 2.29, 2.72, 3.19, 3.07, 0, 4.00, 0, 2.99};
+// Re-measured after the fused Jacobi passes started keeping c1 * b in their rhs window
+// (K - 1 fewer multiplications per point: fp64 K=8 1138 -> 1349 G upd/s, fp32 K=6 1457 -> 1852,
+// fp32 K=10 1371 -> 2019).
+constexpr double kFuseRate64[11] = {0, 1.00, 1.80, 2.45, 3.16, 3.81, 4.80, 0, 5.60, 0, 5.63};
+constexpr double kFuseRate32[11] = {0, 1.00, 1.66, 2.28, 2.80, 3.26, 4.00, 0, 3.75, 0, 4.37};
 // red-black Gauss-Seidel: s sweeps = 2 s levels, s <= 5
 constexpr double kFuseRateGS64[11] = {0, 1.00, 1.81, 2.50, 3.19, 3.12, 0, 0, 0, 0, 0};
 constexpr double kFuseRateGS32[11] = {0, 1.00, 1.79, 2.20, 2.87, 2.69, 0, 0, 0, 0, 0};
@@ -617,7 +623,11 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
 // (post = 1) or the residual norm (post = 2) produced by the last pass.
 // Returns false when this level / configuration is not eligible (caller then
 // uses the stand-alone kernels); on success *norm_blocks = partial sums written.
-inline int fold_kmax(const mgx_solver* s, int N) { return N >= 8192 ? s->fuse.fold_kmax_big : s->fuse.fold_kmax; }
+inline int fold_kmax(const mgx_solver* s, int N, int post = 1)
+{
+    if (post == 0) return s->fuse.fold_kmax_nopost;
+    return N >= 8192 ? s->fuse.fold_kmax_big : s->fuse.fold_kmax;
+}
 
 template <typename T, int SM>
 bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool pre, int post, int* launches,
@@ -644,7 +654,7 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
         return true;
     }
     int parts[64];
-    const int np = plan_fusion(mu, fold_kmax(s, l.N), sizeof(T) == 8, parts, rbgs);
+    const int np = plan_fusion(mu, fold_kmax(s, l.N, post), sizeof(T) == 8, parts, rbgs);
     const T om = (T)s->cfg.omega;
     const T c0 = (T)(1.0 - (double)om);
     const T c1 = (T)((double)om / 4.0);
@@ -673,7 +683,7 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
 }
 
 // pre-check made before any launch (so a `false` never leaves a half-done block)
-bool fold_eligible(const mgx_solver* s, const Level& l, int mu)
+bool fold_eligible(const mgx_solver* s, const Level& l, int mu, int post = 1)
 {
     if (!s->fold || mu < 1 || mu > 64) return false;
     if (tile_level(s, l)) return true;
@@ -682,7 +692,7 @@ bool fold_eligible(const mgx_solver* s, const Level& l, int mu)
     const int per = rbgs ? 2 : 1;
     if (s->fuse.kmax < per) return false;
     int parts[64];
-    const int np = plan_fusion(mu, fold_kmax(s, l.N), l.f64, parts, rbgs);
+    const int np = plan_fusion(mu, fold_kmax(s, l.N, post), l.f64, parts, rbgs);
     for (int p = 0; p < np; ++p)
         if (!cycle_k_supported(per * parts[p], rbgs)) return false;
     // the norm partials of the folded pass must fit the reduction buffer
@@ -708,7 +718,7 @@ bool zero_in_ok(const mgx_solver* s, int level)
 bool smooth_folded(mgx_solver* s, int level, int mu, bool pre, int post, bool zero_in = false)
 {
     Level& l = s->lv[level];
-    if (!fold_eligible(s, l, mu)) return false;
+    if (!fold_eligible(s, l, mu, post)) return false;
     const Level* coarse = (pre || post == 1) ? &s->lv[level - 1] : nullptr;
     const bool fine = (level == s->cfg.finest_level);
     Prof p(s, fine ? MGX_PROF_SMOOTH_FINE : MGX_PROF_COARSE, mu);

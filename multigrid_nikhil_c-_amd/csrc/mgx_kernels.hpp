@@ -159,6 +159,32 @@ __device__ __forceinline__ float4 jacobi_vec<float>(const float4& up, const floa
     return o;
 }
 
+// the same sweep with the rhs already multiplied: cb = c1 * b (the product is rounded
+// once either way, so the result has the same bits).  The fused kernel uses a rhs row
+// at K levels; multiplying it when it is loaded saves K - 1 multiplications per point.
+__device__ __forceinline__ double2 jacobi_vec_pre(const double2& up, const double2& cur, const double2& dn,
+                                                  const double2& cb, double c0, double c1)
+{
+    const double l = from_left(cur.y), r = from_right(cur.x);
+    double2 o;
+    o.x = (c0 * cur.x + cb.x) + c1 * nbr(up.x, l, cur.y, dn.x);
+    o.y = (c0 * cur.y + cb.y) + c1 * nbr(up.y, cur.x, r, dn.y);
+    return o;
+}
+__device__ __forceinline__ float4 jacobi_vec_pre(const float4& up, const float4& cur, const float4& dn,
+                                                 const float4& cb, float c0, float c1)
+{
+    const float l = from_left(cur.w), r = from_right(cur.x);
+    float4 o;
+    o.x = (c0 * cur.x + cb.x) + c1 * nbr(up.x, l, cur.y, dn.x);
+    o.y = (c0 * cur.y + cb.y) + c1 * nbr(up.y, cur.x, cur.z, dn.y);
+    o.z = (c0 * cur.z + cb.z) + c1 * nbr(up.z, cur.y, cur.w, dn.z);
+    o.w = (c0 * cur.w + cb.w) + c1 * nbr(up.w, cur.z, r, dn.w);
+    return o;
+}
+__device__ __forceinline__ double2 vscale(double c, const double2& v) { return make_double2(c * v.x, c * v.y); }
+__device__ __forceinline__ float4 vscale(float c, const float4& v) { return make_float4(c * v.x, c * v.y, c * v.z, c * v.w); }
+
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_jacobi(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
@@ -408,13 +434,16 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
     fused_loads<T, K, EDGE>(nin, nbn, y + 1, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
 #pragma unroll
     for (int j = K - 1; j > 0; --j) bw[j] = bw[j - 1];
-    bw[0] = bn;
+    if constexpr (SM == 0) bw[0] = vscale(c1, bn);       // Jacobi: the window holds c1 * b (see jacobi_vec_pre)
+    else bw[0] = bn;
     lev[0][S_NEW] = in;
 #pragma unroll
     for (int j = 1; j <= K; ++j) {
         // level-j row (y - j) from level-(j-1) rows (y-j-1, y-j, y-j+1) and rhs row y-j
         const int row = y - j;
-        V o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1, par_c + row);
+        V o;
+        if constexpr (SM == 0) o = jacobi_vec_pre(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1);
+        else o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1, par_c + row);
         if (EDGE) {
             mask_cols(o, col, N);
             if (!(row > bnd_lo && row < bnd_hi)) o = Z;          // Dirichlet rows stay zero
@@ -855,15 +884,21 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
         if constexpr (W == 2) { in.x = in.x + add.x; in.y = in.y + add.y; }
         else { in.x = in.x + add.x; in.y = in.y + add.y; in.z = in.z + add.z; in.w = in.w + add.w; }
     }
+    // Jacobi passes without a residual stage keep c1 * b in the window (see jacobi_vec_pre);
+    // the residual of POST needs b itself
+    constexpr bool PREMUL = (SM == 0 && POST == 0);
 #pragma unroll
     for (int j = K; j > 0; --j) bw[j] = bw[j - 1];
-    bw[0] = bn;
+    if constexpr (PREMUL) bw[0] = vscale(c1, bn);
+    else bw[0] = bn;
     lev[0][S_NEW] = in;
 #pragma unroll
     for (int j = 1; j <= K; ++j) {
         const int row = y - j;
-        V o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1,
-                              row + (int)(col & 1));
+        V o;
+        if constexpr (PREMUL) o = jacobi_vec_pre(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1);
+        else o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1,
+                                 row + (int)(col & 1));
         if (EDGE) {
             mask_cols(o, col, N);
             if (!(row > bnd_lo && row < bnd_hi)) o = Z;
