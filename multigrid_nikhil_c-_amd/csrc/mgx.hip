@@ -53,7 +53,12 @@ struct EventPair { hipEvent_t a, b; int cls; long long launches; long long sweep
 
 // temporal fusion knobs: levels per pass, chunk height (0 = by grid size), smallest
 // fused grid, levels per pass for the folded kernels
-struct FuseCfg { int kmax; int rows; int min_n; int fold_kmax; int fold_kmax_big; int tile_max_n; int tile_k; int fold_kmax_nopost; };
+struct FuseCfg {
+    int kmax; int rows; int min_n; int fold_kmax; int fold_kmax_big; int tile_max_n; int tile_k; int fold_kmax_nopost;
+    // explicit pass plans (sweeps per pass) for the pre- / post-smoothing block of grids with
+    // N >= plan_min_n: tuning knobs MGX_PLAN_PRE / MGX_PLAN_POST ("8,2"), MGX_PLAN_MIN_N
+    int plan_pre[8] = {0}; int n_pre = 0; int plan_post[8] = {0}; int n_post = 0; int plan_min_n = 8192;
+};
 
 } // namespace
 
@@ -244,6 +249,22 @@ inline FuseCfg fuse_cfg()
     // levels per folded pass for blocks that end WITHOUT a residual stage (post-smoothing below
     // the finest level): those passes keep c1 * b in their window and are cheaper per level
     f.fold_kmax_nopost = std::max(1, std::min(f.kmax, env_int("MGX_FOLD_KMAX_NOPOST", f.fold_kmax)));
+    auto parse = [](const char* name, int* out) {
+        const char* v = std::getenv(name);
+        int n = 0;
+        while (v && *v && n < 8) {
+            char* end = nullptr;
+            const long k = std::strtol(v, &end, 10);
+            if (end == v || k < 1 || k > 10) return 0;
+            out[n++] = (int)k;
+            v = (*end == ',') ? end + 1 : end;
+            if (*end && *end != ',') return 0;
+        }
+        return n;
+    };
+    f.n_pre = parse("MGX_PLAN_PRE", f.plan_pre);
+    f.n_post = parse("MGX_PLAN_POST", f.plan_post);
+    f.plan_min_n = env_int("MGX_PLAN_MIN_N", 8192);
     return f;
 }
 
@@ -618,16 +639,46 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
     if (parity) std::swap(l.u, l.tmp);
 }
 
-// mu Jacobi sweeps on a whole level with the prolongation+correction applied while
-// loading (pre_e: coarse correction, may be null) and/or the residual restriction
-// (post = 1) or the residual norm (post = 2) produced by the last pass.
-// Returns false when this level / configuration is not eligible (caller then
-// uses the stand-alone kernels); on success *norm_blocks = partial sums written.
 inline int fold_kmax(const mgx_solver* s, int N, int post = 1)
 {
     if (post == 0) return s->fuse.fold_kmax_nopost;
     return N >= 8192 ? s->fuse.fold_kmax_big : s->fuse.fold_kmax;
 }
+
+// The passes (sweeps per pass) of a folded smoothing block: pre-smoothing = (pre false, post 1),
+// post-smoothing = (pre true, post 0 or 2).  An explicit plan wins when it fits; otherwise the
+// DP over the measured rates, capped at the folded kernels' depth.
+int fold_plan(const mgx_solver* s, const Level& l, int mu, bool pre, int post, int* parts)
+{
+    const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
+    const FuseCfg& f = s->fuse;
+    const int* forced = nullptr;
+    int nf = 0;
+    if (!pre && post == 1) { forced = f.plan_pre; nf = f.n_pre; }
+    else if (pre) { forced = f.plan_post; nf = f.n_post; }
+    if (nf > 0 && l.N >= f.plan_min_n) {
+        const int per = rbgs ? 2 : 1;
+        int sum = 0;
+        bool ok = true;
+        for (int i = 0; i < nf; ++i) {
+            sum += forced[i];
+            const int K = per * forced[i];
+            const bool folded = (i == 0 && pre) || (i == nf - 1 && post != 0);
+            ok = ok && K <= 10 && (folded ? cycle_k_supported(K, rbgs) : (K != 7 && K != 9 && (!rbgs || K % 2 == 0)));
+        }
+        if (ok && sum == mu) {
+            for (int i = 0; i < nf; ++i) parts[i] = forced[i];
+            return nf;
+        }
+    }
+    return plan_fusion(mu, fold_kmax(s, l.N, post), l.f64, parts, rbgs);
+}
+
+// mu Jacobi sweeps on a whole level with the prolongation+correction applied while
+// loading (pre_e: coarse correction, may be null) and/or the residual restriction
+// (post = 1) or the residual norm (post = 2) produced by the last pass.
+// Returns false when this level / configuration is not eligible (caller then
+// uses the stand-alone kernels); on success *norm_blocks = partial sums written.
 
 template <typename T, int SM>
 bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool pre, int post, int* launches,
@@ -654,7 +705,7 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
         return true;
     }
     int parts[64];
-    const int np = plan_fusion(mu, fold_kmax(s, l.N, post), sizeof(T) == 8, parts, rbgs);
+    const int np = fold_plan(s, l, mu, pre, post, parts);
     const T om = (T)s->cfg.omega;
     const T c0 = (T)(1.0 - (double)om);
     const T c1 = (T)((double)om / 4.0);
@@ -683,7 +734,7 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
 }
 
 // pre-check made before any launch (so a `false` never leaves a half-done block)
-bool fold_eligible(const mgx_solver* s, const Level& l, int mu, int post = 1)
+bool fold_eligible(const mgx_solver* s, const Level& l, int mu, bool pre = false, int post = 1)
 {
     if (!s->fold || mu < 1 || mu > 64) return false;
     if (tile_level(s, l)) return true;
@@ -692,7 +743,7 @@ bool fold_eligible(const mgx_solver* s, const Level& l, int mu, int post = 1)
     const int per = rbgs ? 2 : 1;
     if (s->fuse.kmax < per) return false;
     int parts[64];
-    const int np = plan_fusion(mu, fold_kmax(s, l.N, post), l.f64, parts, rbgs);
+    const int np = fold_plan(s, l, mu, pre, post, parts);
     for (int p = 0; p < np; ++p)
         if (!cycle_k_supported(per * parts[p], rbgs)) return false;
     // the norm partials of the folded pass must fit the reduction buffer
@@ -711,14 +762,14 @@ bool zero_in_ok(const mgx_solver* s, int level)
     if (tile_level(s, l)) return true;
     const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
     int parts[64];
-    const int np = plan_fusion(mu, fold_kmax(s, l.N), l.f64, parts, rbgs);
+    const int np = fold_plan(s, l, mu, false, 1, parts);
     return !(np >= 2 && !rbgs && parts[0] == 1);      // a leading plain single Jacobi sweep reads its input
 }
 
 bool smooth_folded(mgx_solver* s, int level, int mu, bool pre, int post, bool zero_in = false)
 {
     Level& l = s->lv[level];
-    if (!fold_eligible(s, l, mu, post)) return false;
+    if (!fold_eligible(s, l, mu, pre, post)) return false;
     const Level* coarse = (pre || post == 1) ? &s->lv[level - 1] : nullptr;
     const bool fine = (level == s->cfg.finest_level);
     Prof p(s, fine ? MGX_PROF_SMOOTH_FINE : MGX_PROF_COARSE, mu);
