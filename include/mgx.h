@@ -189,6 +189,11 @@ MGX_API int mgx_profile_get(mgx_handle h, mgx_profile* out);
  * handle's stream; returns the elapsed milliseconds. */
 MGX_API int mgx_time_smoother(mgx_handle h, int sweeps, double* ms);
 MGX_API int mgx_synchronize(mgx_handle h);
+/* Number of hipGraphs mgx_solve has captured for its loop body ("one V-cycle +
+ * residual norm", PS:727 run to a tolerance): 0 until the first graph cycle,
+ * -1 when graph replay is off (cfg.profile = 1, mixed precision, MGX_GRAPH=0,
+ * or a failed capture). */
+MGX_API int mgx_graphs_cached(mgx_handle h);
 
 /* =============================================================================
  * Slab-level operators on caller-owned device memory.  These are what the

@@ -34,7 +34,7 @@ EXPORTS = [
     "mgx_get_level", "mgx_set_level_device", "mgx_get_level_device", "mgx_zero_level", "mgx_fill_rhs", "mgx_fill_guess_random", "mgx_smooth", "mgx_residual",
     "mgx_restrict", "mgx_restrict_rhs", "mgx_prolong_add", "mgx_prolong", "mgx_bottom_solve",
     "mgx_residual_norm", "mgx_vcycle", "mgx_fmg", "mgx_solve", "mgx_profile_reset",
-    "mgx_profile_get", "mgx_time_smoother", "mgx_synchronize", "mgx_level_pitch",
+    "mgx_profile_get", "mgx_time_smoother", "mgx_synchronize", "mgx_graphs_cached", "mgx_level_pitch",
     "mgx_slab_jacobi", "mgx_slab_rbgs", "mgx_slab_restrict", "mgx_slab_prolong",
     "mgx_slab_residual_sumsq", "mgx_slab_scratch_doubles",
 ]
@@ -109,7 +109,7 @@ def lib() -> C.CDLL:
     L.mgx_smooth.argtypes = [vp, C.c_int, C.c_int]
     for name in ("mgx_residual", "mgx_restrict", "mgx_restrict_rhs", "mgx_prolong_add", "mgx_prolong", "mgx_vcycle"):
         getattr(L, name).argtypes = [vp, C.c_int]
-    for name in ("mgx_bottom_solve", "mgx_fmg", "mgx_profile_reset", "mgx_synchronize"):
+    for name in ("mgx_bottom_solve", "mgx_fmg", "mgx_profile_reset", "mgx_synchronize", "mgx_graphs_cached"):
         getattr(L, name).argtypes = [vp]
     L.mgx_residual_norm.argtypes = [vp, C.c_int, dp]
     L.mgx_solve.argtypes = [vp, C.c_double, C.c_int, C.POINTER(Stats), dp, C.c_int]
@@ -321,6 +321,10 @@ class Multigrid:
         ms = C.c_double()
         self._chk(lib().mgx_time_smoother(self._h, sweeps, C.byref(ms)), "mgx_time_smoother")
         return ms.value
+
+    def graphs_cached(self):
+        """hipGraphs captured by solve() for its loop body (-1: graph replay off)"""
+        return lib().mgx_graphs_cached(self._h)
 
     def synchronize(self):
         self._chk(lib().mgx_synchronize(self._h), "mgx_synchronize")

@@ -89,6 +89,14 @@ struct mgx_solver {
     bool want_norm = false;         // the top-level post-smoothing should also produce ||r||^2 partials
     int norm_blocks_ready = 0;      // > 0: partial[] holds that many sums of r^2 for the current U
     double fine_updates = 0.0;
+    // hipGraph replay of "one V-cycle + residual norm" in mgx_solve (profiling off only)
+    struct CycleGraph {
+        std::vector<void*> before, after;   // u / tmp of every level before and after the cycle
+        hipGraphExec_t exec = nullptr;
+        double fine_updates = 0.0;
+    };
+    std::vector<CycleGraph> graphs;
+    int use_graph = 1;              // MGX_GRAPH
 
     int fail(int code, const std::string& m) { err = m; return code; }
 };
@@ -899,8 +907,8 @@ int fmg(mgx_solver* s)
     return MGX_OK;
 }
 
-// ||B - A U|| of an arbitrary grid pair (double or float)
-int residual_norm_grid(mgx_solver* s, const Level& l, const void* u, const void* b, double* out, int cls)
+// ||B - A U||^2 of an arbitrary grid pair (double or float) -> sum_host, enqueued only
+int enqueue_norm(mgx_solver* s, const Level& l, const void* u, const void* b, int cls)
 {
     if (s->norm_blocks_ready > 0 && u == s->lv[s->cfg.finest_level].u && !s->mixed) {
         // the last post-smoothing pass already summed (b - A u)^2 per block
@@ -918,8 +926,96 @@ int residual_norm_grid(mgx_solver* s, const Level& l, const void* u, const void*
     }
     s->norm_blocks_ready = 0;
     HIPCHK(s, hipMemcpyAsync(s->sum_host, s->sum_dev, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    return MGX_OK;
+}
+
+int residual_norm_grid(mgx_solver* s, const Level& l, const void* u, const void* b, double* out, int cls)
+{
+    int rc = enqueue_norm(s, l, u, b, cls);
+    if (rc) return rc;
     HIPCHK(s, hipStreamSynchronize(s->stream));
     *out = std::sqrt(*s->sum_host);
+    return MGX_OK;
+}
+
+// ---- mgx_solve's loop body: one V-cycle from the finest level + the residual norm -----------
+// About 30 launches, the small levels launch-bound: with profiling off the whole body is
+// captured once into a hipGraph and replayed.  The cycle swaps each level's u / tmp buffers
+// on the host, so a graph is keyed by the buffer assignment it was captured with and carries
+// the assignment it leaves behind (a cycle with an odd number of passes on some level
+// alternates between two graphs).
+std::vector<void*> buffer_state(const mgx_solver* s)
+{
+    std::vector<void*> v;
+    for (int l = s->cfg.coarsest_level; l <= s->cfg.finest_level; ++l) { v.push_back(s->lv[l].u); v.push_back(s->lv[l].tmp); }
+    return v;
+}
+
+void set_buffer_state(mgx_solver* s, const std::vector<void*>& v)
+{
+    size_t i = 0;
+    for (int l = s->cfg.coarsest_level; l <= s->cfg.finest_level; ++l) { s->lv[l].u = v[i++]; s->lv[l].tmp = v[i++]; }
+}
+
+int cycle_and_norm_direct(mgx_solver* s, double* r)
+{
+    const int L = s->cfg.finest_level;
+    Level& l = s->lv[L];
+    s->norm_blocks_ready = 0;
+    s->want_norm = true; s->zero_in_level = -1;
+    vcycle(s, L);
+    s->want_norm = false;
+    return residual_norm_grid(s, l, l.u, l.b, r, MGX_PROF_NORM_FINE);
+}
+
+int cycle_and_norm(mgx_solver* s, double* r)
+{
+    if (!s->use_graph || s->cfg.profile || s->mixed) return cycle_and_norm_direct(s, r);
+    const int L = s->cfg.finest_level;
+    const std::vector<void*> before = buffer_state(s);
+    mgx_solver::CycleGraph* g = nullptr;
+    for (auto& c : s->graphs)
+        if (c.before == before) { g = &c; break; }
+    if (!g) {
+        if (s->graphs.size() >= 8) return cycle_and_norm_direct(s, r);
+        const double fu0 = s->fine_updates;
+        if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            s->use_graph = 0;
+            return cycle_and_norm_direct(s, r);
+        }
+        // enqueue the body (nothing executes while capturing; the host-side bookkeeping does)
+        s->norm_blocks_ready = 0;
+        s->want_norm = true; s->zero_in_level = -1;
+        vcycle(s, L);
+        s->want_norm = false;
+        const int rc = enqueue_norm(s, s->lv[L], s->lv[L].u, s->lv[L].b, MGX_PROF_NORM_FINE);
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipError_t e = hipStreamEndCapture(s->stream, &graph);
+        if (rc == MGX_OK && e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (rc != MGX_OK || e != hipSuccess) {
+            // undo the bookkeeping of the cycle that was not run, and stay on the direct path
+            (void)hipGetLastError();
+            set_buffer_state(s, before);
+            s->fine_updates = fu0;
+            s->use_graph = 0;
+            return cycle_and_norm_direct(s, r);
+        }
+        mgx_solver::CycleGraph c;
+        c.before = before; c.after = buffer_state(s); c.exec = exec; c.fine_updates = s->fine_updates - fu0;
+        s->graphs.push_back(c);
+        g = &s->graphs.back();
+    } else {
+        set_buffer_state(s, g->after);
+        s->fine_updates += g->fine_updates;
+    }
+    s->norm_blocks_ready = 0;
+    s->zero_in_level = -1;
+    HIPCHK(s, hipGraphLaunch(g->exec, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    *r = std::sqrt(*s->sum_host);
     return MGX_OK;
 }
 
@@ -1044,6 +1140,7 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
     s->fuse = fuse_cfg();
     s->fold = env_int("MGX_FOLD", 1);
     s->use_zero_in = env_int("MGX_ZERO_IN", 1);
+    s->use_graph = env_int("MGX_GRAPH", 1);
     int rc = MGX_OK;
     auto bail = [&](int code) { g_create_error = s->err; mgx_destroy(s); return code; };
     if (hipStreamCreate(&s->stream) != hipSuccess) { s->err = "hipStreamCreate failed"; return bail(MGX_ERR_HIP); }
@@ -1090,11 +1187,19 @@ int mgx_destroy(mgx_handle s)
     if (s->partial) (void)hipFree(s->partial);
     if (s->sum_dev) (void)hipFree(s->sum_dev);
     if (s->sum_host) (void)hipHostFree(s->sum_host);
+    for (auto& g : s->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (auto& p : s->ev_used) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : s->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return MGX_OK;
+}
+
+int mgx_graphs_cached(mgx_handle s)
+{
+    if (!s) return MGX_ERR_INVALID;
+    if (!s->use_graph || s->cfg.profile || s->mixed) return -1;
+    return (int)s->graphs.size();
 }
 
 int mgx_synchronize(mgx_handle s)
@@ -1336,9 +1441,12 @@ int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double
         for (k = 0; k < max_cycles; ++k) {
             if (hist[k] <= tol * hist[0]) break;
             s->norm_blocks_ready = 0;
-            if (k == 0 && do_fmg) { if ((rc = fmg(s))) return rc; }
-            else { s->want_norm = true; s->zero_in_level = -1; vcycle(s, L); s->want_norm = false; }
-            if ((rc = residual_norm_grid(s, l, l.u, l.b, &r, MGX_PROF_NORM_FINE))) return rc;
+            if (k == 0 && do_fmg) {
+                if ((rc = fmg(s))) return rc;
+                if ((rc = residual_norm_grid(s, l, l.u, l.b, &r, MGX_PROF_NORM_FINE))) return rc;
+            } else if ((rc = cycle_and_norm(s, &r))) {
+                return rc;
+            }
             hist.push_back(r);
         }
     } else {

@@ -285,3 +285,60 @@ def test_seeded_fuzz_of_configurations_against_the_oracle(pkg, po, monkeypatch):
         floor = 32 * np.finfo(np.float64).eps * scale * n
         assert hist_close(h, h_ref, rtol, floor), (case, cfg, h, h_ref)
         assert np.max(np.abs(u - u_ref)) <= (1e-7 if cfg["dtype"] == 2 else 1e-10) * scale, (case, cfg)
+
+
+GRAPH_CASES = [
+    # the reference's own hierarchy, tiles on every level: an even number of passes per level
+    (dict(finest_level=10, coarsest_level=7, mu1=10, mu2=10, schedule=0), {}),
+    # marching kernels with explicit plans: three passes down, two up -> the buffers alternate
+    (dict(finest_level=10, coarsest_level=6, mu1=4, mu2=3, schedule=0),
+     {"MGX_TILE_MAX_N": "0", "MGX_PLAN_MIN_N": "256", "MGX_PLAN_PRE": "1,1,2", "MGX_PLAN_POST": "2,1"}),
+    (dict(finest_level=9, coarsest_level=5, mu1=3, mu2=2, schedule=0, smoother=1), {}),
+    (dict(finest_level=11, coarsest_level=8, mu1=2, mu2=1, schedule=0, dtype=0), {}),
+    (dict(finest_level=9, coarsest_level=6, mu1=1, mu2=1, schedule=0, bottom=1), {"MGX_FOLD": "0"}),
+    (dict(finest_level=9, coarsest_level=6, mu0=0, mu1=2, mu2=2, schedule=1), {}),
+]
+
+
+@pytest.mark.parametrize("case", range(len(GRAPH_CASES)))
+def test_graph_replay_of_the_cycle_is_bit_identical(pkg, po, monkeypatch, case):
+    """mgx_solve replays "V-cycle + residual norm" from a hipGraph when profiling is off.  The
+    graph is keyed by the u/tmp buffer assignment of every level, so: several solves on one
+    handle, a cycle with an odd number of passes (assignment alternates), an API call between
+    solves that flips a buffer, FMG followed by V-cycles - all must give exactly the bits and
+    the history of the direct path (MGX_GRAPH=0)."""
+    cfg, env = GRAPH_CASES[case]
+    L = cfg["finest_level"]
+    n = (1 << L) - 1
+    dt = np.float32 if cfg.get("dtype", 1) == 0 else np.float64
+    b = po.rhs_sine(L).astype(dt)
+    u0 = po.fill_uniform((n, n), 77).astype(dt)
+    u1 = po.fill_uniform((n, n), 78).astype(dt)
+    for k in ("MGX_TILE_MAX_N", "MGX_PLAN_MIN_N", "MGX_PLAN_PRE", "MGX_PLAN_POST", "MGX_FOLD", "MGX_GRAPH"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    out = {}
+    for graph in ("0", "1"):
+        monkeypatch.setenv("MGX_GRAPH", graph)
+        res = []
+        with pkg.Multigrid(**cfg) as mg:
+            mg.set_rhs(b)
+            mg.set_guess(u0)
+            st, h = mg.solve(tol=0.0, max_cycles=5)
+            res += [np.array(h), mg.get_solution(), st.fine_updates]
+            # a single sweep through the operator API flips the finest level's buffers
+            mg.set_guess(u1)
+            mg.smooth(L, 1)
+            st, h = mg.solve(tol=0.0, max_cycles=4)
+            res += [np.array(h), mg.get_solution(), st.fine_updates]
+            st, h = mg.solve(tol=1e-6, max_cycles=30)
+            res += [np.array(h), mg.get_solution(), st.fine_updates, st.cycles]
+            # the graph path really ran (1 graph, or 2-3 when the buffer assignment alternates)
+            assert mg.graphs_cached() == -1 if graph == "0" else 1 <= mg.graphs_cached() <= 4
+        out[graph] = res
+    for a, c in zip(out["0"], out["1"]):
+        assert np.array_equal(a, c)
+    if dt == np.float64 and cfg.get("schedule", 0) == 0:
+        _, h_ref = po.Solver(**cfg).solve(b.astype(np.float64), u0.astype(np.float64), tol=0.0, max_cycles=5)
+        assert hist_close(out["1"][0], h_ref)
