@@ -97,6 +97,7 @@ struct mgx_solver {
     };
     std::vector<CycleGraph> graphs;
     int use_graph = 1;              // MGX_GRAPH
+    int mixed_fuse = 1;             // mixed precision: u += s e and the residual in one pass (MGX_MIXED_FUSE)
 
     int fail(int code, const std::string& m) { err = m; return code; }
 };
@@ -1148,7 +1149,9 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
     for (int l = cfg->coarsest_level; l <= cfg->finest_level; ++l)
         if ((rc = alloc_level(s, s->lv[l], l, s->work_f64)) != MGX_OK) return bail(rc);
     if (s->mixed && (rc = alloc_level(s, s->fine64, cfg->finest_level, true)) != MGX_OK) return bail(rc);
-    if (s->mixed) { (void)hipFree(s->fine64.tmp); s->fine64.tmp = nullptr; }
+    s->mixed_fuse = env_int("MGX_MIXED_FUSE", 1);
+    // fine64.tmp: the out-of-place target of the fused update + residual pass
+    if (s->mixed && !s->mixed_fuse) { (void)hipFree(s->fine64.tmp); s->fine64.tmp = nullptr; }
     // partial sums: the largest launch any norm kernel can make on the finest level
     {
         const int N = 1 << cfg->finest_level;
@@ -1461,6 +1464,7 @@ int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double
         for (k = 0; k < max_cycles; ++k) {
             if (hist[k] <= tol * hist[0]) break;
             const Launch g = make_launch(d.N, 2, d.N - 1, rpc);
+            double pending_scale = 0.0;
             if (k == 0 && do_fmg) {
                 // ||b||: residual norm against a zero guess (FMG discards the guess, PS:630)
                 HIPCHK(s, hipMemsetAsync(d.u, 0, d.bytes, s->stream));
@@ -1484,8 +1488,12 @@ int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double
                 if (zero_in_ok(s, L)) s->zero_in_level = L;
                 else HIPCHK(s, hipMemsetAsync(w.u, 0, w.bytes, s->stream));
                 vcycle(s, L);
-                hipLaunchKernelGGL(k_axpy_f32_to_f64, dim3(g.blocks), dim3(kBlock), 0, s->stream, (double*)d.u,
-                                   (const float*)w.u, scale, d.N, d.pitch, w.pitch, 1, d.N, g.R, g.strips, g.chunks, 0);
+                pending_scale = scale;                        // u += scale * e still to be applied
+                if (!(s->mixed_fuse && d.tmp)) {
+                    hipLaunchKernelGGL(k_axpy_f32_to_f64, dim3(g.blocks), dim3(kBlock), 0, s->stream, (double*)d.u,
+                                       (const float*)w.u, scale, d.N, d.pitch, w.pitch, 1, d.N, g.R, g.strips, g.chunks, 0);
+                    pending_scale = 0.0;
+                }
             }
             // residual of the new iterate: its norm is hist[k+1]; the same pass
             // writes the float residual the next cycle consumes, scaled by the
@@ -1493,8 +1501,22 @@ int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double
             {
                 const double next_scale = pow2_floor(hist[k] / n);
                 Prof p(s, MGX_PROF_NORM_FINE, 2);
-                launch_residual<double, 2>((const double*)d.u, (const double*)d.b, w.b, w.pitch, s->partial,
-                                           s->sum_dev, 1.0 / next_scale, d.N, d.pitch, 1, d.N, rpc, s->stream, s->partial_cap);
+                if (pending_scale != 0.0) {
+                    // the correction and the residual in one out-of-place pass (32 instead of 40 B per point)
+                    Launch gr = make_launch(d.N, 2, d.N - 1, rpc);
+                    if (gr.blocks > s->partial_cap) {
+                        const int R = (int)(((long)gr.strips * (d.N - 1) / kWavesPerBlock + s->partial_cap - 9) / (s->partial_cap - 8)) + 1;
+                        gr = make_launch(d.N, 2, d.N - 1, R);
+                    }
+                    hipLaunchKernelGGL(k_update_residual, dim3(gr.blocks), dim3(kBlock), 0, s->stream, (const double*)d.u,
+                                       (const float*)w.u, (const double*)d.b, (double*)d.tmp, (float*)w.b, pending_scale,
+                                       1.0 / next_scale, s->partial, d.N, d.pitch, w.pitch, 1, d.N, gr.R, gr.strips, gr.chunks);
+                    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, s->stream, s->partial, gr.blocks, s->sum_dev);
+                    std::swap(d.u, d.tmp);
+                } else {
+                    launch_residual<double, 2>((const double*)d.u, (const double*)d.b, w.b, w.pitch, s->partial,
+                                               s->sum_dev, 1.0 / next_scale, d.N, d.pitch, 1, d.N, rpc, s->stream, s->partial_cap);
+                }
             }
             HIPCHK(s, hipMemcpyAsync(s->sum_host, s->sum_dev, sizeof(double), hipMemcpyDeviceToHost, s->stream));
             HIPCHK(s, hipStreamSynchronize(s->stream));

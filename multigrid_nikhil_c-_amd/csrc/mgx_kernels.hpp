@@ -1265,6 +1265,63 @@ k_axpy_f32_to_f64(double* __restrict__ u, const float* __restrict__ e, double sc
     }
 }
 
+// mixed precision, the two fp64 passes of a cycle in one: unew = u + scale * (double) e
+// (k_axpy_f32_to_f64) and, of that new iterate, r = b - A unew: sum r^2 -> partial[] and
+// (float)(r * inv_scale) -> r32 (k_residual<double, 2>).  Out of place: a chunk reads its
+// neighbours' edge rows of u, which an in-place update would race with.  Same expressions,
+// same launch geometry and summation order as the two kernels it replaces: same bits.
+// Algorithmic bytes per point: 8 (u) + 4 (e) + 8 (b) + 8 (unew) + 4 (r32) = 32 (separately: 40).
+__global__ void __launch_bounds__(kBlock)
+k_update_residual(const double* __restrict__ u, const float* __restrict__ e, const double* __restrict__ rhs,
+                  double* __restrict__ unew, float* __restrict__ r32, double scale, double inv_scale,
+                  double* __restrict__ partial, int N, long pitch, long epitch, int row_lo, int row_hi,
+                  int R, int strips, int chunks)
+{
+    __shared__ double wsum[kWavesPerBlock];
+    const Tile t = wave_tile(strips, chunks);
+    double acc = 0.0;
+    if (t.active) {
+        const Cols c = lane_cols<2>(t.strip, N, pitch);
+        const int r0 = row_lo + t.chunk * R;
+        const int r1 = min(r0 + R, row_hi);
+        // updated row r (rows 0 and N, column 0 and the padding hold zeros in u and e and stay zero)
+        auto updated = [&](int r) {
+            double2 o = make_double2(0.0, 0.0);
+            if (c.ld) {
+                const double2 uv = *reinterpret_cast<const double2*>(u + (long)r * pitch + c.col);
+                const float2 ev = *reinterpret_cast<const float2*>(e + (long)r * epitch + c.col);
+                o.x = uv.x + scale * (double)ev.x;
+                o.y = uv.y + scale * (double)ev.y;
+                if (c.col == 0) o.x = 0.0;
+            }
+            return o;
+        };
+        double2 up = updated(r0 - 1);
+        double2 cur = updated(r0);
+        for (int r = r0; r < r1; ++r) {
+            const double2 dn = updated(r + 1);
+            const double2 bb = vload<double2>(rhs + (long)r * pitch + c.col, c.ld);
+            double2 o = residual_vec(up, cur, dn, bb);
+            mask_cols(o, c.col, N);
+            if (c.st) {
+                *reinterpret_cast<double2*>(unew + (long)r * pitch + c.col) = cur;
+                acc += (double)o.x * (double)o.x + (double)o.y * (double)o.y;
+                *reinterpret_cast<float2*>(r32 + (long)r * epitch + c.col) =
+                    make_float2((float)(o.x * inv_scale), (float)(o.y * inv_scale));
+            }
+            up = cur; cur = dn;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < kWavesPerBlock; ++w) s += wsum[w];
+        partial[blockIdx.x] = s;
+    }
+}
+
 // f64 grid -> f32 grid with scaling (mixed FMG right-hand side)
 __global__ void __launch_bounds__(kBlock)
 k_scale_f64_to_f32(float* __restrict__ out, const double* __restrict__ in, double inv_scale, int N, long pitch_in, long pitch_out,

@@ -342,3 +342,24 @@ def test_graph_replay_of_the_cycle_is_bit_identical(pkg, po, monkeypatch, case):
     if dt == np.float64 and cfg.get("schedule", 0) == 0:
         _, h_ref = po.Solver(**cfg).solve(b.astype(np.float64), u0.astype(np.float64), tol=0.0, max_cycles=5)
         assert hist_close(out["1"][0], h_ref)
+
+
+@pytest.mark.parametrize("schedule", [0, 1])
+def test_mixed_update_and_residual_in_one_pass_is_bit_identical(pkg, po, monkeypatch, schedule):
+    """config 5: k_update_residual (u += s e and r = b - A u, out of place, 32 B per point) against
+    the two kernels it replaces (MGX_MIXED_FUSE=0): same double solution, same history"""
+    cfg = dict(finest_level=10, coarsest_level=7, mu0=0, mu1=2, mu2=1, schedule=schedule, dtype=2)
+    b = po.rhs_sine(10)
+    u0 = None if schedule else po.fill_uniform(b.shape, 31)
+    out = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("MGX_MIXED_FUSE", fuse)
+        st, h, u = run_gpu(pkg, cfg, b, u0, tol=1e-10, max_cycles=25)
+        out[fuse] = (np.array(h), u, st.cycles)
+    assert out["0"][2] == out["1"][2]
+    assert np.array_equal(out["0"][0], out["1"][0])
+    assert np.array_equal(out["0"][1], out["1"][1])
+    # the float inner cycle follows the oracle's to 1e-3 per cycle over the first cycles (the exact
+    # bottom solves differ in the last float digit and the difference compounds afterwards)
+    _, h_ref = po.Solver(**cfg).solve(b, u0, tol=1e-10, max_cycles=25)
+    assert hist_close(out["1"][0][:6], h_ref[:6], 1e-3)
