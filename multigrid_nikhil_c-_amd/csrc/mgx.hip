@@ -285,7 +285,9 @@ inline FuseCfg fuse_cfg()
 // (K - 1 fewer multiplications per point: fp64 K=8 1138 -> 1349 G upd/s, fp32 K=6 1457 -> 1852,
 // fp32 K=10 1371 -> 2019).
 constexpr double kFuseRate64[11] = {0, 1.00, 1.80, 2.45, 3.16, 3.81, 4.80, 0, 5.60, 0, 5.63};
-constexpr double kFuseRate32[11] = {0, 1.00, 1.66, 2.28, 2.80, 3.26, 4.00, 0, 3.75, 0, 4.37};
+// float again after the row operators were written on pairs (all arithmetic packed:
+// v_pk_add_f32 / v_pk_mul_f32): K=5 1508 -> 1743, K=8 1731 -> 2301 G upd/s.
+constexpr double kFuseRate32[11] = {0, 1.00, 1.67, 2.38, 3.10, 3.77, 4.26, 0, 4.98, 0, 4.67};
 // red-black Gauss-Seidel: s sweeps = 2 s levels, s <= 5
 constexpr double kFuseRateGS64[11] = {0, 1.00, 1.81, 2.50, 3.19, 3.12, 0, 0, 0, 0, 0};
 constexpr double kFuseRateGS32[11] = {0, 1.00, 1.79, 2.20, 2.87, 2.69, 0, 0, 0, 0, 0};
@@ -402,8 +404,12 @@ int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, i
         case 4: return launch_cycle_k<T, 4, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
         case 6: return launch_cycle_k<T, 6, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
         case 8: return launch_cycle_k<T, 8, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
-        case 10: return launch_cycle_k<T, 10, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
         default: break;
+    }
+    // 10 levels with folded stages: double only (the float variants, whose packed arithmetic
+    // needs aligned register pairs, exceed 256 VGPRs)
+    if constexpr (sizeof(T) == 8) {
+        if (K == 10) return launch_cycle_k<T, 10, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
     }
     if constexpr (SM == 0) {
         switch (K) {
@@ -417,9 +423,10 @@ int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, i
 }
 
 // levels per pass the folded kernels are instantiated for
-inline bool cycle_k_supported(int K, bool rbgs)
+inline bool cycle_k_supported(int K, bool rbgs, bool f64)
 {
-    return rbgs ? (K == 2 || K == 4 || K == 6 || K == 8 || K == 10) : ((K >= 1 && K <= 8 && K != 7) || K == 10);
+    if (K == 10) return f64;
+    return rbgs ? (K == 2 || K == 4 || K == 6 || K == 8) : (K >= 1 && K <= 8 && K != 7);
 }
 
 // ---- small levels: every sweep of a block in one launch on register tiles (k_tile_smooth) ----
@@ -648,10 +655,11 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
     if (parity) std::swap(l.u, l.tmp);
 }
 
-inline int fold_kmax(const mgx_solver* s, int N, int post = 1)
+inline int fold_kmax(const mgx_solver* s, int N, int post = 1, bool f64 = true)
 {
-    if (post == 0) return s->fuse.fold_kmax_nopost;
-    return N >= 8192 ? s->fuse.fold_kmax_big : s->fuse.fold_kmax;
+    int k = N >= 8192 ? s->fuse.fold_kmax_big : s->fuse.fold_kmax;
+    if (post == 0) k = s->fuse.fold_kmax_nopost;
+    return f64 ? k : std::min(k, 8);           // no 10-level folded kernels in float
 }
 
 // The passes (sweeps per pass) of a folded smoothing block: pre-smoothing = (pre false, post 1),
@@ -673,14 +681,14 @@ int fold_plan(const mgx_solver* s, const Level& l, int mu, bool pre, int post, i
             sum += forced[i];
             const int K = per * forced[i];
             const bool folded = (i == 0 && pre) || (i == nf - 1 && post != 0);
-            ok = ok && K <= 10 && (folded ? cycle_k_supported(K, rbgs) : (K != 7 && K != 9 && (!rbgs || K % 2 == 0)));
+            ok = ok && K <= 10 && (folded ? cycle_k_supported(K, rbgs, l.f64) : (K != 7 && K != 9 && (!rbgs || K % 2 == 0)));
         }
         if (ok && sum == mu) {
             for (int i = 0; i < nf; ++i) parts[i] = forced[i];
             return nf;
         }
     }
-    return plan_fusion(mu, fold_kmax(s, l.N, post), l.f64, parts, rbgs);
+    return plan_fusion(mu, fold_kmax(s, l.N, post, l.f64), l.f64, parts, rbgs);
 }
 
 // mu Jacobi sweeps on a whole level with the prolongation+correction applied while
@@ -754,7 +762,7 @@ bool fold_eligible(const mgx_solver* s, const Level& l, int mu, bool pre = false
     int parts[64];
     const int np = fold_plan(s, l, mu, pre, post, parts);
     for (int p = 0; p < np; ++p)
-        if (!cycle_k_supported(per * parts[p], rbgs)) return false;
+        if (!cycle_k_supported(per * parts[p], rbgs, l.f64)) return false;
     // the norm partials of the folded pass must fit the reduction buffer
     return true;
 }

@@ -136,6 +136,23 @@ __device__ __forceinline__ typename VecOf<T>::type
 jacobi_vec(const typename VecOf<T>::type& up, const typename VecOf<T>::type& cur,
            const typename VecOf<T>::type& dn, const typename VecOf<T>::type& bb, T c0, T c1);
 
+// fp32 rows are processed as two pairs so that every operation is a packed
+// v_pk_add_f32 / v_pk_mul_f32 (IEEE per component: same bits as the scalar form, and the
+// off-diagonal sum keeps the order ((N + W) + E) + S).  With cur = (x, y, z, w), l / r the
+// neighbours' w / x:  W = (l, x | y, z),  E = (y, z | w, r).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct NbrPairs { f32x2 t0, t1; };
+__device__ __forceinline__ NbrPairs nbr_pairs(const float4& up, const float4& cur, const float4& dn)
+{
+    const float l = from_left(cur.w), r = from_right(cur.x);
+    const f32x2 n0 = {up.x, up.y}, n1 = {up.z, up.w}, s0 = {dn.x, dn.y}, s1 = {dn.z, dn.w};
+    const f32x2 A = {l, cur.x}, B = {cur.y, cur.z}, C = {cur.w, r};
+    NbrPairs p;
+    p.t0 = ((n0 + A) + B) + s0;
+    p.t1 = ((n1 + B) + C) + s1;
+    return p;
+}
+
 template <>
 __device__ __forceinline__ double2 jacobi_vec<double>(const double2& up, const double2& cur, const double2& dn,
                                                       const double2& bb, double c0, double c1)
@@ -150,13 +167,11 @@ template <>
 __device__ __forceinline__ float4 jacobi_vec<float>(const float4& up, const float4& cur, const float4& dn,
                                                     const float4& bb, float c0, float c1)
 {
-    const float l = from_left(cur.w), r = from_right(cur.x);
-    float4 o;
-    o.x = (c0 * cur.x + c1 * bb.x) + c1 * nbr(up.x, l, cur.y, dn.x);
-    o.y = (c0 * cur.y + c1 * bb.y) + c1 * nbr(up.y, cur.x, cur.z, dn.y);
-    o.z = (c0 * cur.z + c1 * bb.z) + c1 * nbr(up.z, cur.y, cur.w, dn.z);
-    o.w = (c0 * cur.w + c1 * bb.w) + c1 * nbr(up.w, cur.z, r, dn.w);
-    return o;
+    const NbrPairs t = nbr_pairs(up, cur, dn);
+    const f32x2 p0 = {cur.x, cur.y}, p1 = {cur.z, cur.w}, b0 = {bb.x, bb.y}, b1 = {bb.z, bb.w};
+    const f32x2 o0 = (c0 * p0 + c1 * b0) + c1 * t.t0;
+    const f32x2 o1 = (c0 * p1 + c1 * b1) + c1 * t.t1;
+    return make_float4(o0.x, o0.y, o1.x, o1.y);
 }
 
 // the same sweep with the rhs already multiplied: cb = c1 * b (the product is rounded
@@ -174,13 +189,11 @@ __device__ __forceinline__ double2 jacobi_vec_pre(const double2& up, const doubl
 __device__ __forceinline__ float4 jacobi_vec_pre(const float4& up, const float4& cur, const float4& dn,
                                                  const float4& cb, float c0, float c1)
 {
-    const float l = from_left(cur.w), r = from_right(cur.x);
-    float4 o;
-    o.x = (c0 * cur.x + cb.x) + c1 * nbr(up.x, l, cur.y, dn.x);
-    o.y = (c0 * cur.y + cb.y) + c1 * nbr(up.y, cur.x, cur.z, dn.y);
-    o.z = (c0 * cur.z + cb.z) + c1 * nbr(up.z, cur.y, cur.w, dn.z);
-    o.w = (c0 * cur.w + cb.w) + c1 * nbr(up.w, cur.z, r, dn.w);
-    return o;
+    const NbrPairs t = nbr_pairs(up, cur, dn);
+    const f32x2 p0 = {cur.x, cur.y}, p1 = {cur.z, cur.w}, b0 = {cb.x, cb.y}, b1 = {cb.z, cb.w};
+    const f32x2 o0 = (c0 * p0 + b0) + c1 * t.t0;
+    const f32x2 o1 = (c0 * p1 + b1) + c1 * t.t1;
+    return make_float4(o0.x, o0.y, o1.x, o1.y);
 }
 __device__ __forceinline__ double2 vscale(double c, const double2& v) { return make_double2(c * v.x, c * v.y); }
 __device__ __forceinline__ float4 vscale(float c, const float4& v) { return make_float4(c * v.x, c * v.y, c * v.z, c * v.w); }
@@ -280,12 +293,14 @@ template <int COLOUR>
 __device__ __forceinline__ float4 gs_colour_f(const float4& up, const float4& cur, const float4& dn,
                                               const float4& bb, int par0)
 {
-    const float l = from_left(cur.w), r = from_right(cur.x);
+    const NbrPairs t = nbr_pairs(up, cur, dn);
+    const f32x2 b0 = {bb.x, bb.y}, b1 = {bb.z, bb.w};
+    const f32x2 c0 = 0.25f * (b0 + t.t0), c1 = 0.25f * (b1 + t.t1);
     float4 o;
-    o.x = gs_pick<float, COLOUR>(cur.x, 0.25f * (bb.x + nbr(up.x, l, cur.y, dn.x)), par0);
-    o.y = gs_pick<float, COLOUR>(cur.y, 0.25f * (bb.y + nbr(up.y, cur.x, cur.z, dn.y)), par0 + 1);
-    o.z = gs_pick<float, COLOUR>(cur.z, 0.25f * (bb.z + nbr(up.z, cur.y, cur.w, dn.z)), par0);
-    o.w = gs_pick<float, COLOUR>(cur.w, 0.25f * (bb.w + nbr(up.w, cur.z, r, dn.w)), par0 + 1);
+    o.x = gs_pick<float, COLOUR>(cur.x, c0.x, par0);
+    o.y = gs_pick<float, COLOUR>(cur.y, c0.y, par0 + 1);
+    o.z = gs_pick<float, COLOUR>(cur.z, c1.x, par0);
+    o.w = gs_pick<float, COLOUR>(cur.w, c1.y, par0 + 1);
     return o;
 }
 template <int COLOUR> __device__ __forceinline__ double2
@@ -530,13 +545,11 @@ __device__ __forceinline__ double2 residual_vec(const double2& up, const double2
 }
 __device__ __forceinline__ float4 residual_vec(const float4& up, const float4& cur, const float4& dn, const float4& bb)
 {
-    const float l = from_left(cur.w), r = from_right(cur.x);
-    float4 o;
-    o.x = bb.x - (-nbr(up.x, l, cur.y, dn.x) + 4.f * cur.x);
-    o.y = bb.y - (-nbr(up.y, cur.x, cur.z, dn.y) + 4.f * cur.y);
-    o.z = bb.z - (-nbr(up.z, cur.y, cur.w, dn.z) + 4.f * cur.z);
-    o.w = bb.w - (-nbr(up.w, cur.z, r, dn.w) + 4.f * cur.w);
-    return o;
+    const NbrPairs t = nbr_pairs(up, cur, dn);
+    const f32x2 p0 = {cur.x, cur.y}, p1 = {cur.z, cur.w}, b0 = {bb.x, bb.y}, b1 = {bb.z, bb.w};
+    const f32x2 o0 = b0 - (-t.t0 + 4.f * p0);
+    const f32x2 o1 = b1 - (-t.t1 + 4.f * p1);
+    return make_float4(o0.x, o0.y, o1.x, o1.y);
 }
 
 // MODE 0: store r (same type).  MODE 1: accumulate sum r^2 only.
