@@ -235,7 +235,8 @@ def test_tuning_knobs_never_change_a_bit(pkg, po, monkeypatch, smoother):
     knobs += [{"MGX_TILE_MAX_N": "0", "MGX_PLAN_MIN_N": "256", "MGX_PLAN_PRE": "3,1", "MGX_PLAN_POST": "1,2"},
               {"MGX_TILE_MAX_N": "0", "MGX_PLAN_MIN_N": "256", "MGX_PLAN_PRE": "1,1,2", "MGX_PLAN_POST": "2,1"},
               {"MGX_TILE_MAX_N": "0", "MGX_PLAN_MIN_N": "256", "MGX_PLAN_PRE": "4", "MGX_PLAN_POST": "3"},
-              {"MGX_TILE_MAX_N": "0", "MGX_FOLD_KMAX_NOPOST": "10", "MGX_FOLD_KMAX": "2"}]
+              {"MGX_TILE_MAX_N": "0", "MGX_FOLD_KMAX_NOPOST": "10", "MGX_FOLD_KMAX": "2"},
+              {"MGX_TILE_MAX_N": "0", "MGX_FOLD_KMAX_NOPOST": "5"}, {"MGX_TILE_MAX_N": "0", "MGX_FOLD_KMAX_NOPOST": "2"}]
     ref = None
     for kn in knobs:
         for k in ("MGX_FUSE", "MGX_ROWS", "MGX_FOLD", "MGX_FOLD_KMAX", "MGX_FUSE_ROWS", "MGX_FUSE_MIN_N", "MGX_ZERO_IN",
