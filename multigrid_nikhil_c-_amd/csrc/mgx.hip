@@ -661,7 +661,8 @@ inline int fold_kmax(const mgx_solver* s, int N, int post = 1, bool f64 = true)
     // double Jacobi blocks that end without a residual stage (post-smoothing below the finest
     // level) keep c1 * b in their window and run deeper: one <10,PRE,0> pass instead of two;
     // -38 .. -45 us of the coarse levels of a V(10,10) cycle at 8192^2 on three boxes
-    if (post == 0 && f64 && s->cfg.smoother == MGX_SMOOTHER_JACOBI) k = s->fuse.fold_kmax_nopost;
+    // (4096^2: 200 us against 121 + 98; at 2048^2 the two shallow passes win, 69 against 76 us)
+    if (post == 0 && f64 && N >= 4096 && s->cfg.smoother == MGX_SMOOTHER_JACOBI) k = s->fuse.fold_kmax_nopost;
     return f64 ? k : std::min(k, 8);           // no 10-level folded kernels in float
 }
 
