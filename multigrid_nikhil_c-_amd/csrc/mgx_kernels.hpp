@@ -432,6 +432,8 @@ fused_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
     }
 }
 
+constexpr int kPrefetch = 3;      // rows a marching wave loads ahead (= the rotation period)
+
 template <typename T, int K, int SM, bool EDGE, int P>
 __device__ __forceinline__ void
 fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K],
@@ -442,11 +444,13 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
     using V = typename VecOf<T>::type;
     constexpr int S_OLD = (P + 1) % 3, S_MID = (P + 2) % 3, S_NEW = P;
     const V Z = vzero((V*)nullptr);
-    // level 0: input row y and rhs row y-1 were loaded during the previous step
-    // (software prefetch: on small grids there is ~1 wave per CU and nothing else
-    // hides the load latency); issue the next step's loads before computing
+    // level 0: input row y and rhs row y-1 were loaded three steps ago into this phase's
+    // prefetch slot (each rotation phase owns one slot, so the prefetch queue needs no
+    // register moves either); refill the slot with the rows of step y+3 before computing.
+    // Three rows in flight per wave instead of one: a marching wave has no other way to
+    // cover the HBM latency.
     const V in = nin, bn = nbn;
-    fused_loads<T, K, EDGE>(nin, nbn, y + 1, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
+    fused_loads<T, K, EDGE>(nin, nbn, y + kPrefetch, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
 #pragma unroll
     for (int j = K - 1; j > 0; --j) bw[j] = bw[j - 1];
     if constexpr (SM == 0) bw[0] = vscale(c1, bn);       // Jacobi: the window holds c1 * b (see jacobi_vec_pre)
@@ -482,16 +486,18 @@ fused_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     const int par_c = row_parity + (int)(col & 1);
     // steps y = r0-K .. r1+K-1, rounded up to a multiple of 3 (the extra steps
     // store nothing; in the EDGE body their loads are predicated, in the
-    // interior body the caller guarantees three more rows exist below the cone:
-    // two for the rounding, one for the prefetch)
+    // interior body the caller guarantees five more rows exist below the cone:
+    // two for the rounding, three for the prefetch)
     const int y0 = r0 - K;
     const int steps = (r1 + K - y0 + 2) / 3 * 3;
-    V nin, nbn;
-    fused_loads<T, K, EDGE>(nin, nbn, y0, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
+    V nin[kPrefetch], nbn[kPrefetch];
+#pragma unroll
+    for (int q = 0; q < kPrefetch; ++q)
+        fused_loads<T, K, EDGE>(nin[q], nbn[q], y0 + q, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
     for (int y = y0; y < y0 + steps; y += 3) {
-        fused_step<T, K, SM, EDGE, 0>(lev, bw, nin, nbn, y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
-        fused_step<T, K, SM, EDGE, 1>(lev, bw, nin, nbn, y + 1, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
-        fused_step<T, K, SM, EDGE, 2>(lev, bw, nin, nbn, y + 2, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
+        fused_step<T, K, SM, EDGE, 0>(lev, bw, nin[0], nbn[0], y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
+        fused_step<T, K, SM, EDGE, 1>(lev, bw, nin[1], nbn[1], y + 1, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
+        fused_step<T, K, SM, EDGE, 2>(lev, bw, nin[2], nbn[2], y + 2, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
     }
 }
 
@@ -519,13 +525,13 @@ k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     // Rows that may be dereferenced at all: inside the allocation AND not beyond a
     // global boundary row (on a slab the allocation ends long before the boundary).
     const int rd_lo = max(bnd_lo, 0), rd_hi = min(bnd_hi, rows_alloc - 1);
-    // wave-uniform: does everything the unpredicated body touches - rows r0-K-1 .. r1+K+2
-    // (the step count is rounded up to a multiple of 3, plus one prefetched row), vectors one
+    // wave-uniform: does everything the unpredicated body touches - rows r0-K-1 .. r1+K+4
+    // (the step count is rounded up to a multiple of 3, plus three prefetched rows), vectors one
     // beyond the first and last lane - lie strictly inside the unknowns and inside the allocation?
     const int vx0 = t.strip * OUT - HL;
     const bool interior = (vx0 >= 1) && ((long)(vx0 + kWave) * W < N) &&
                           (r0 - K - 1 > bnd_lo) && (r0 - K - 1 >= 0) &&
-                          (r1 + K + 3 < bnd_hi) && (r1 + K + 3 <= rows_alloc - 1);
+                          (r1 + K + 2 + kPrefetch < bnd_hi) && (r1 + K + 2 + kPrefetch <= rows_alloc - 1);
     if (interior) fused_body<T, K, SM, false>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, zero_in != 0);
     else fused_body<T, K, SM, true>(pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, zero_in != 0);
 }
@@ -871,7 +877,7 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     // prefetch, see fused_step); issue the next step's loads before computing
     V in = nin;
     const V bn = nbn;
-    cycle_loads<T, EDGE>(nin, nbn, y + 1, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in);
+    cycle_loads<T, EDGE>(nin, nbn, y + kPrefetch, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in);
     if (PRE) {
         // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624).  The coarse
         // values of row y were fetched during the previous step (pe.a = coarse row y>>1,
@@ -1003,16 +1009,18 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     const int y0 = r0 - K - ETOP;
     ca.y_end = r1 + K + EBOT;                       // exclusive end of the steps that matter
     const int steps = (ca.y_end - y0 + 2) / 3 * 3;  // rounded up to whole rotations
-    V nin, nbn;
-    cycle_loads<T, EDGE>(nin, nbn, y0, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in);
+    V nin[kPrefetch], nbn[kPrefetch];
+#pragma unroll
+    for (int q = 0; q < kPrefetch; ++q)
+        cycle_loads<T, EDGE>(nin[q], nbn[q], y0 + q, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in);
     PreFetch<T, CW> pe;
 #pragma unroll
     for (int k = 0; k <= CW; ++k) { pe.a[k] = (T)0; pe.b[k] = (T)0; }
     if (PRE) coarse_loads<T, EDGE>(pe, y0, coarse_e, cpitch, ccol, N, cld);
     for (int y = y0; y < y0 + steps; y += 3) {
-        cycle_step<T, K, PRE, POST, SM, EDGE, 0>(lev, bw, nin, nbn, pe, cs, y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
-        cycle_step<T, K, PRE, POST, SM, EDGE, 1>(lev, bw, nin, nbn, pe, cs, y + 1, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
-        cycle_step<T, K, PRE, POST, SM, EDGE, 2>(lev, bw, nin, nbn, pe, cs, y + 2, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
+        cycle_step<T, K, PRE, POST, SM, EDGE, 0>(lev, bw, nin[0], nbn[0], pe, cs, y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
+        cycle_step<T, K, PRE, POST, SM, EDGE, 1>(lev, bw, nin[1], nbn[1], pe, cs, y + 1, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
+        cycle_step<T, K, PRE, POST, SM, EDGE, 2>(lev, bw, nin[2], nbn[2], pe, cs, y + 2, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
     }
     return cs.acc;
 }
@@ -1043,11 +1051,11 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         const bool st = (lane >= HL) && (lane < kWave - HL) && (vx < N / W);
         const int r0 = row_lo + t.chunk * R;
         const int r1 = min(r0 + R, row_hi);
-        // everything the unpredicated body touches (rows r0-K-ETOP-1 .. r1+K+EBOT+2: rotation
-        // rounding plus one prefetched row; one vector beyond the first and last lane; the
+        // everything the unpredicated body touches (rows r0-K-ETOP-1 .. r1+K+EBOT+4: rotation
+        // rounding plus three prefetched rows; one vector beyond the first and last lane; the
         // matching coarse rows/columns) strictly inside
         const bool interior = (vx0 >= 1) && ((long)(vx0 + kWave + 1) * W < N) &&
-                              (r0 - K - ETOP - 1 > 0) && (r1 + K + EBOT + 3 < N);
+                              (r0 - K - ETOP - 1 > 0) && (r1 + K + EBOT + 2 + kPrefetch < N);
         if (interior)
             acc = cycle_body<T, K, PRE, POST, SM, false>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
                                                          pitch, cpitch, col, N, r0, r1, true, st, c0, c1, zero_in != 0);
