@@ -432,12 +432,13 @@ fused_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
     }
 }
 
-constexpr int kPrefetch = 3;      // rows a marching wave loads ahead (= the rotation period)
+constexpr int kPfStages = 1;                 // prefetch slots per rotation phase (2 = six rows ahead: measured slower)
+constexpr int kPrefetch = 3 * kPfStages;     // rows a marching wave loads ahead
 
 template <typename T, int K, int SM, bool EDGE, int P>
 __device__ __forceinline__ void
 fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K],
-           typename VecOf<T>::type& nin, typename VecOf<T>::type& nbn, int y,
+           typename VecOf<T>::type (&nin)[kPfStages], typename VecOf<T>::type (&nbn)[kPfStages], int y,
            const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po, long pitch, long col, int N,
            int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int par_c, bool zero_in)
 {
@@ -449,8 +450,10 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
     // register moves either); refill the slot with the rows of step y+3 before computing.
     // Three rows in flight per wave instead of one: a marching wave has no other way to
     // cover the HBM latency.
-    const V in = nin, bn = nbn;
-    fused_loads<T, K, EDGE>(nin, nbn, y + kPrefetch, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
+    const V in = nin[0], bn = nbn[0];
+#pragma unroll
+    for (int q = 0; q + 1 < kPfStages; ++q) { nin[q] = nin[q + 1]; nbn[q] = nbn[q + 1]; }
+    fused_loads<T, K, EDGE>(nin[kPfStages - 1], nbn[kPfStages - 1], y + kPrefetch, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
 #pragma unroll
     for (int j = K - 1; j > 0; --j) bw[j] = bw[j - 1];
     if constexpr (SM == 0) bw[0] = vscale(c1, bn);       // Jacobi: the window holds c1 * b (see jacobi_vec_pre)
@@ -490,10 +493,10 @@ fused_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     // two for the rounding, three for the prefetch)
     const int y0 = r0 - K;
     const int steps = (r1 + K - y0 + 2) / 3 * 3;
-    V nin[kPrefetch], nbn[kPrefetch];
+    V nin[3][kPfStages], nbn[3][kPfStages];        // [rotation phase][queue position]
 #pragma unroll
     for (int q = 0; q < kPrefetch; ++q)
-        fused_loads<T, K, EDGE>(nin[q], nbn[q], y0 + q, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
+        fused_loads<T, K, EDGE>(nin[q % 3][q / 3], nbn[q % 3][q / 3], y0 + q, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
     for (int y = y0; y < y0 + steps; y += 3) {
         fused_step<T, K, SM, EDGE, 0>(lev, bw, nin[0], nbn[0], y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
         fused_step<T, K, SM, EDGE, 1>(lev, bw, nin[1], nbn[1], y + 1, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
@@ -858,7 +861,7 @@ cycle_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
 template <typename T, int K, int PRE, int POST, int SM, bool EDGE, int P>
 __device__ __forceinline__ void
 cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&bw)[K + 1],
-           typename VecOf<T>::type& nin, typename VecOf<T>::type& nbn, PreFetch<T, VecOf<T>::W / 2>& pe,
+           typename VecOf<T>::type (&nin)[kPfStages], typename VecOf<T>::type (&nbn)[kPfStages], PreFetch<T, VecOf<T>::W / 2>& pe,
            CycleState<T, VecOf<T>::W / 2>& cs, int y,
            const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
            const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
@@ -875,9 +878,11 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
 
     // input row y and rhs row y-1 were loaded during the previous step (software
     // prefetch, see fused_step); issue the next step's loads before computing
-    V in = nin;
-    const V bn = nbn;
-    cycle_loads<T, EDGE>(nin, nbn, y + kPrefetch, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in);
+    V in = nin[0];
+    const V bn = nbn[0];
+#pragma unroll
+    for (int q = 0; q + 1 < kPfStages; ++q) { nin[q] = nin[q + 1]; nbn[q] = nbn[q + 1]; }
+    cycle_loads<T, EDGE>(nin[kPfStages - 1], nbn[kPfStages - 1], y + kPrefetch, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in);
     if (PRE) {
         // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624).  The coarse
         // values of row y were fetched during the previous step (pe.a = coarse row y>>1,
@@ -1009,10 +1014,10 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     const int y0 = r0 - K - ETOP;
     ca.y_end = r1 + K + EBOT;                       // exclusive end of the steps that matter
     const int steps = (ca.y_end - y0 + 2) / 3 * 3;  // rounded up to whole rotations
-    V nin[kPrefetch], nbn[kPrefetch];
+    V nin[3][kPfStages], nbn[3][kPfStages];        // [rotation phase][queue position]
 #pragma unroll
     for (int q = 0; q < kPrefetch; ++q)
-        cycle_loads<T, EDGE>(nin[q], nbn[q], y0 + q, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in);
+        cycle_loads<T, EDGE>(nin[q % 3][q / 3], nbn[q % 3][q / 3], y0 + q, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in);
     PreFetch<T, CW> pe;
 #pragma unroll
     for (int k = 0; k <= CW; ++k) { pe.a[k] = (T)0; pe.b[k] = (T)0; }
