@@ -364,3 +364,29 @@ def test_mixed_update_and_residual_in_one_pass_is_bit_identical(pkg, po, monkeyp
     # bottom solves differ in the last float digit and the difference compounds afterwards)
     _, h_ref = po.Solver(**cfg).solve(b, u0, tol=1e-10, max_cycles=25)
     assert hist_close(out["1"][0][:6], h_ref[:6], 1e-3)
+
+
+FULL_SIZE = [
+    # BASELINE config 2 exactly: 4096^2, six levels, Jacobi V(2,1)
+    ("config2", dict(finest_level=12, coarsest_level=7, mu1=2, mu2=1, schedule=0), 3),
+    # the bench's own workload: 8192^2, levels 13..7, the reference's V(10,10)
+    ("bench", dict(finest_level=13, coarsest_level=7, mu1=10, mu2=10, schedule=0), 2),
+    # BASELINE config 3: 8192^2 red-black Gauss-Seidel
+    ("config3", dict(finest_level=13, coarsest_level=7, mu1=2, mu2=1, schedule=0, smoother=1), 2),
+]
+
+
+@pytest.mark.parametrize("name,cfg,cycles", FULL_SIZE, ids=[c[0] for c in FULL_SIZE])
+def test_full_size_cycles_against_the_oracle(pkg, po, name, cfg, cycles):
+    """BASELINE's full sizes against the oracle itself (its OpenMP build finishes these in
+    seconds): residual history to 1e-10 relative per cycle (north_star), iterate to 1e-12 of
+    its maximum (the grid operators are bit-exact; the two exact bottom solves differ in the
+    last digits)."""
+    L = cfg["finest_level"]
+    n = (1 << L) - 1
+    b = po.rhs_sine(L)
+    u0 = po.fill_uniform((n, n), 12345)
+    st, h, u = run_gpu(pkg, cfg, b, u0, tol=0.0, max_cycles=cycles)
+    u_ref, h_ref = po.Solver(**cfg).solve(b, u0, tol=0.0, max_cycles=cycles)
+    assert hist_close(h, h_ref), (h, h_ref)
+    assert np.max(np.abs(u - u_ref)) <= 1e-12 * np.max(np.abs(u_ref))
