@@ -114,3 +114,23 @@ def test_poisson_driver_binary_runs_the_reference_sequence(pkg):
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("solve to 1e-8")][0]
     assert "u(1/2,1/2) = 0.29468" in out.stdout
     assert int(line.split()[3]) <= 16
+
+
+def test_config4_grid_slab_driver_equals_single_gpu_solve(pkg, po):
+    """BASELINE config 4's grid (16384^2, levels 14..7) through the slab driver exactly as
+    bench.py --gpus N sets it up (levels 14..12 on slabs, <= 11 in the replicated handle),
+    world 1 on this one GPU: the reference's V(10,10) cycle must reproduce mgx_solve bit for bit"""
+    import gc
+
+    cfg = dict(finest=14, cut=11, coarsest=7, mu1=10, mu2=10, omega=2.0 / 3.0, smoother="jacobi")
+    mg, b, u0 = _setup(pkg, po, cfg)
+    hist = [mg.residual_norm()]
+    mg.vcycle()
+    hist.append(mg.residual_norm())
+    own = mg.own_interior("u").cpu().numpy()
+    del mg
+    gc.collect()
+    h_ref, u_ref = _single(pkg, cfg, b, u0, 1)
+    assert np.array_equal(own, u_ref)
+    assert np.allclose(hist, h_ref, rtol=1e-13, atol=0)
+    assert hist[1] < 0.1 * hist[0]
