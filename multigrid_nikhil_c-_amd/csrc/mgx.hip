@@ -389,9 +389,10 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
     const long waves = (long)g.strips * g.chunks;
     g.blocks = (int)(((waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
+    const CycleWin win{0, N, 0, N / 2, 1, N / 2};          // a whole grid
     hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout,
                        (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
-                       1, N, g.R, g.strips, g.chunks, c0, c1, fa.zero_in);
+                       1, N, g.R, g.strips, g.chunks, c0, c1, fa.zero_in, win);
     return g.blocks;
 }
 

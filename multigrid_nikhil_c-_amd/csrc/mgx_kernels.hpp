@@ -813,10 +813,21 @@ template <typename T, int CW> struct CycleState {
     double acc;                 // POST 2: sum of r^2
 };
 
+// The rows that exist in memory, in GLOBAL row numbers (whole grid: 0..N and 0..N/2; a slab
+// of a row-decomposed grid: its rows incl. halos - the kernel is then given base pointers
+// moved back by row0 rows, so that global numbers index them), and the coarse rows POST = 1
+// may write (whole grid: 1..N/2-1; slab: the coarse rows this rank owns).
+struct CycleWin {
+    int row_first, row_last;        // fine rows [row_first, row_last] exist
+    int crow_first, crow_last;      // coarse rows [crow_first, crow_last] exist
+    int emit_lo, emit_hi;           // coarse rows [emit_lo, emit_hi) are written
+};
+
 struct CycleArgs {              // what the stages besides the smoother need (uniform)
     long cpitch; int NC;
     int r0, r1, y_end;
     bool zero_in;               // the input iterate is all zero: do not read it
+    CycleWin win;
 };
 
 // one row step of k_jacobi_cycle at window-rotation phase P (see fused_step)
@@ -826,11 +837,12 @@ template <typename T, int CW> struct PreFetch { T a[CW + 1], b[CW + 1]; };
 
 template <typename T, bool EDGE>
 __device__ __forceinline__ void
-coarse_loads(PreFetch<T, VecOf<T>::W / 2>& pe, int y, const T* __restrict__ coarse_e, long cpitch, long ccol, int N, bool cld)
+coarse_loads(PreFetch<T, VecOf<T>::W / 2>& pe, int y, const T* __restrict__ coarse_e, long cpitch, long ccol, int N, bool cld,
+             const CycleWin& win)
 {
     constexpr int CW = VecOf<T>::W / 2;
     const int I = y >> 1;
-    const bool cl = EDGE ? (cld && y > 0 && y < N) : true;
+    const bool cl = EDGE ? (cld && y > 0 && y < N && I >= win.crow_first && I + (y & 1) <= win.crow_last) : true;
     const T* p = coarse_e + (long)I * cpitch + ccol;
 #pragma unroll
     for (int k = 0; k <= CW; ++k) pe.a[k] = cl ? p[k] : (T)0;
@@ -845,12 +857,15 @@ coarse_loads(PreFetch<T, VecOf<T>::W / 2>& pe, int y, const T* __restrict__ coar
 template <typename T, bool EDGE>
 __device__ __forceinline__ void
 cycle_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
-            const T* __restrict__ pv, const T* __restrict__ pb, long pitch, int N, int y_end, bool ld, bool zero_in)
+            const T* __restrict__ pv, const T* __restrict__ pb, long pitch, int N, int y_end, bool ld, bool zero_in,
+            const CycleWin& win)
 {
     using V = typename VecOf<T>::type;
     if (EDGE) {
-        in = vload<V>(pv + (long)y * pitch, ld && !zero_in && y >= 0 && y <= N && y < y_end);
-        bn = vload<V>(pb + (long)(y - 1) * pitch, ld && (y - 1) > 0 && (y - 1) < N && y <= y_end);
+        // win.row_first >= 0 and win.row_last <= N: the window also keeps y inside the grid
+        in = vload<V>(pv + (long)y * pitch, ld && !zero_in && y >= win.row_first && y <= win.row_last && y < y_end);
+        bn = vload<V>(pb + (long)(y - 1) * pitch, ld && (y - 1) > 0 && (y - 1) < N && (y - 1) >= win.row_first &&
+                                                   (y - 1) <= win.row_last && y <= y_end);
     } else {
         in = vzero((V*)nullptr);
         if (!zero_in) in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
@@ -882,7 +897,7 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     const V bn = nbn[0];
 #pragma unroll
     for (int q = 0; q + 1 < kPfStages; ++q) { nin[q] = nin[q + 1]; nbn[q] = nbn[q + 1]; }
-    cycle_loads<T, EDGE>(nin[kPfStages - 1], nbn[kPfStages - 1], y + kPrefetch, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in);
+    cycle_loads<T, EDGE>(nin[kPfStages - 1], nbn[kPfStages - 1], y + kPrefetch, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win);
     if (PRE) {
         // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624).  The coarse
         // values of row y were fetched during the previous step (pe.a = coarse row y>>1,
@@ -890,7 +905,7 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
         T a[CW + 1], b2[CW + 1], o[W];
 #pragma unroll
         for (int k = 0; k <= CW; ++k) { a[k] = pe.a[k]; b2[k] = pe.b[k]; }
-        coarse_loads<T, EDGE>(pe, y + 1, coarse_e, ca.cpitch, ccol, N, cld);
+        coarse_loads<T, EDGE>(pe, y + 1, coarse_e, ca.cpitch, ccol, N, cld, ca.win);
         if ((y & 1) == 0) {
 #pragma unroll
             for (int k = 0; k < CW; ++k) { o[2 * k] = a[k]; o[2 * k + 1] = (T)0.5 * (a[k] + a[k + 1]); }
@@ -955,7 +970,7 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
             // state as a stack array (scratch).
             const bool odd = (rho & 1) != 0;
             const int I = (rho - 1) >> 1;
-            const bool emit = odd && (2 * I >= r0) && (2 * I < r1) && I >= 1 && I < ca.NC;
+            const bool emit = odd && (2 * I >= r0) && (2 * I < r1) && I >= ca.win.emit_lo && I < ca.win.emit_hi;
             T o[CW];
 #pragma unroll
             for (int k = 0; k < CW; ++k) {
@@ -988,7 +1003,8 @@ template <typename T, int K, int PRE, int POST, int SM, bool EDGE>
 __device__ __forceinline__ double
 cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
            const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
-           long pitch, long cpitch, long col, int N, int r0, int r1, bool ld, bool st, T c0, T c1, bool zero_in)
+           long pitch, long cpitch, long col, int N, int r0, int r1, bool ld, bool st, T c0, T c1, bool zero_in,
+           const CycleWin& win)
 {
     using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
@@ -1010,18 +1026,18 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
         cs.ml[k] = cs.mc[k] = cs.mr[k] = (T)0;
     }
     CycleArgs ca;
-    ca.cpitch = cpitch; ca.NC = N / 2; ca.r0 = r0; ca.r1 = r1; ca.zero_in = zero_in;
+    ca.cpitch = cpitch; ca.NC = N / 2; ca.r0 = r0; ca.r1 = r1; ca.zero_in = zero_in; ca.win = win;
     const int y0 = r0 - K - ETOP;
     ca.y_end = r1 + K + EBOT;                       // exclusive end of the steps that matter
     const int steps = (ca.y_end - y0 + 2) / 3 * 3;  // rounded up to whole rotations
     V nin[3][kPfStages], nbn[3][kPfStages];        // [rotation phase][queue position]
 #pragma unroll
     for (int q = 0; q < kPrefetch; ++q)
-        cycle_loads<T, EDGE>(nin[q % 3][q / 3], nbn[q % 3][q / 3], y0 + q, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in);
+        cycle_loads<T, EDGE>(nin[q % 3][q / 3], nbn[q % 3][q / 3], y0 + q, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win);
     PreFetch<T, CW> pe;
 #pragma unroll
     for (int k = 0; k <= CW; ++k) { pe.a[k] = (T)0; pe.b[k] = (T)0; }
-    if (PRE) coarse_loads<T, EDGE>(pe, y0, coarse_e, cpitch, ccol, N, cld);
+    if (PRE) coarse_loads<T, EDGE>(pe, y0, coarse_e, cpitch, ccol, N, cld, ca.win);
     for (int y = y0; y < y0 + steps; y += 3) {
         cycle_step<T, K, PRE, POST, SM, EDGE, 0>(lev, bw, nin[0], nbn[0], pe, cs, y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
         cycle_step<T, K, PRE, POST, SM, EDGE, 1>(lev, bw, nin[1], nbn[1], pe, cs, y + 1, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
@@ -1036,7 +1052,8 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
                const T* __restrict__ coarse_e,                       // PRE
                T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,   // POST == 1
                double* __restrict__ partial,                          // POST == 2
-               int N, long pitch, long cpitch, int row_lo, int row_hi, int R, int strips, int chunks, T c0, T c1, int zero_in)
+               int N, long pitch, long cpitch, int row_lo, int row_hi, int R, int strips, int chunks, T c0, T c1, int zero_in,
+               CycleWin win)
 {
     constexpr int W = VecOf<T>::W;
     constexpr int XC = cycle_halo_cols<K, POST>();
@@ -1056,17 +1073,19 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         const bool st = (lane >= HL) && (lane < kWave - HL) && (vx < N / W);
         const int r0 = row_lo + t.chunk * R;
         const int r1 = min(r0 + R, row_hi);
-        // everything the unpredicated body touches (rows r0-K-ETOP-1 .. r1+K+EBOT+4: rotation
-        // rounding plus three prefetched rows; one vector beyond the first and last lane; the
-        // matching coarse rows/columns) strictly inside
-        const bool interior = (vx0 >= 1) && ((long)(vx0 + kWave + 1) * W < N) &&
-                              (r0 - K - ETOP - 1 > 0) && (r1 + K + EBOT + 2 + kPrefetch < N);
+        // everything the unpredicated body touches (rows r0-K-ETOP-1 .. r1+K+EBOT+1+kPrefetch:
+        // rotation rounding plus the prefetched rows; one vector beyond the first and last lane;
+        // the matching coarse rows/columns) strictly inside the grid and inside the window
+        const int y_first = r0 - K - ETOP - 1, y_lastp = r1 + K + EBOT + 1 + kPrefetch;
+        bool interior = (vx0 >= 1) && ((long)(vx0 + kWave + 1) * W < N) &&
+                        (y_first > 0) && (y_lastp < N) && (y_first >= win.row_first) && (y_lastp <= win.row_last);
+        if (PRE) interior = interior && (y_first >> 1) >= win.crow_first && ((y_lastp >> 1) + 1) <= win.crow_last;
         if (interior)
             acc = cycle_body<T, K, PRE, POST, SM, false>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
-                                                         pitch, cpitch, col, N, r0, r1, true, st, c0, c1, zero_in != 0);
+                                                         pitch, cpitch, col, N, r0, r1, true, st, c0, c1, zero_in != 0, win);
         else
             acc = cycle_body<T, K, PRE, POST, SM, true>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
-                                                        pitch, cpitch, col, N, r0, r1, ld, st, c0, c1, zero_in != 0);
+                                                        pitch, cpitch, col, N, r0, r1, ld, st, c0, c1, zero_in != 0, win);
     }
     if (POST == 2) {
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
