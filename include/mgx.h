@@ -228,6 +228,23 @@ MGX_API int mgx_slab_jacobi(const mgx_slab* s, void* u, const void* b, void* tmp
 MGX_API int mgx_slab_rbgs(const mgx_slab* s, void* u, const void* b, void* tmp,
                           int row_lo, int row_hi, int mu, int shrink,
                           int* result_in_tmp, void* stream);
+/* mu smoother sweeps (PS:125-147 / red-black GS) on local rows [row_lo,row_hi) with the
+ * deep-halo shrinking of mgx_slab_jacobi(shrink = 1) and the V-cycle's transfer operators
+ * folded into the passes, as the single-GPU handle does (one pass over the slab per 5 sweeps
+ * instead of separate transfer kernels):
+ *   coarse_e != NULL : the input is u + P e (PS:620-624), e on the coarse slab `c`;
+ *   coarse_b != NULL : the residual of the result is restricted (PS:604-611) into coarse_b,
+ *                      local coarse rows [crow_lo,crow_hi) of `c` (row_lo + row0 must be odd);
+ *   sum_dev  != NULL : sum over [row_lo,row_hi) of (b - A u)^2 of the result -> *sum_dev
+ *                      (scratch as for mgx_slab_residual_sumsq).
+ * At most one of coarse_b / sum_dev.  The rows the passes read must hold valid data:
+ * per*mu rows beyond the range, +2 with coarse_b, +1 with sum_dev (per = 1 Jacobi, 2 RB-GS),
+ * and with coarse_e the coarse rows around them. */
+MGX_API int mgx_slab_cycle(const mgx_slab* f, void* u, const void* b, void* tmp,
+                           int row_lo, int row_hi, int mu, double omega, int smoother,
+                           const mgx_slab* c, const void* coarse_e, void* coarse_b,
+                           int crow_lo, int crow_hi, int restrict_mode,
+                           double* scratch, double* sum_dev, int* result_in_tmp, void* stream);
 /* fused residual + restriction (PS:604-611) of fine slab `f` into coarse slab
  * `c`, coarse local rows [crow_lo,crow_hi); zero_u (may be NULL) is the coarse
  * solution slab to zero on the same rows (PS:613). */

@@ -34,7 +34,7 @@ EXPORTS = [
     "mgx_get_level", "mgx_set_level_device", "mgx_get_level_device", "mgx_zero_level", "mgx_fill_rhs", "mgx_fill_guess_random", "mgx_smooth", "mgx_residual",
     "mgx_restrict", "mgx_restrict_rhs", "mgx_prolong_add", "mgx_prolong", "mgx_bottom_solve",
     "mgx_residual_norm", "mgx_vcycle", "mgx_fmg", "mgx_solve", "mgx_profile_reset",
-    "mgx_profile_get", "mgx_time_smoother", "mgx_synchronize", "mgx_graphs_cached", "mgx_level_pitch",
+    "mgx_profile_get", "mgx_time_smoother", "mgx_synchronize", "mgx_graphs_cached", "mgx_slab_cycle", "mgx_level_pitch",
     "mgx_slab_jacobi", "mgx_slab_rbgs", "mgx_slab_restrict", "mgx_slab_prolong",
     "mgx_slab_residual_sumsq", "mgx_slab_scratch_doubles",
 ]
@@ -118,6 +118,8 @@ def lib() -> C.CDLL:
     sp = C.POINTER(Slab)
     L.mgx_slab_jacobi.argtypes = [sp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, ip, vp]
     L.mgx_slab_rbgs.argtypes = [sp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, vp]
+    L.mgx_slab_cycle.argtypes = [sp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, sp, vp, vp,
+                                 C.c_int, C.c_int, C.c_int, vp, vp, ip, vp]
     L.mgx_slab_restrict.argtypes = [sp, vp, vp, sp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.mgx_slab_prolong.argtypes = [sp, vp, sp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.mgx_slab_residual_sumsq.argtypes = [sp, vp, vp, C.c_int, C.c_int, vp, vp, vp]

@@ -376,6 +376,10 @@ struct FoldArgs {
     double* partial = nullptr;        // POST 2: per-block sums of r^2
     long cpitch = 0;
     int zero_in = 0;                  // the input iterate is all zero: the pass does not read it
+    // rows to update, GLOBAL numbers, and the window of rows that exist; row_hi == 0: the whole
+    // grid (rows 1..N-1, window 0..N).  Slabs pass base pointers moved back by row0 rows.
+    int row_lo = 0, row_hi = 0;
+    CycleWin win{0, 0, 0, 0, 0, 0};
 };
 
 template <typename T, int K, int PRE, int POST, int SM>
@@ -384,15 +388,18 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
 {
     constexpr int OUT = cycle_out_lanes<K, POST, VecOf<T>::W>();
     if (R & 1) ++R;                                    // chunks must start on odd rows (POST = 1)
-    Launch g = make_launch(N, VecOf<T>::W, N - 1, R);
+    const bool whole = (fa.row_hi == 0);
+    const int row_lo = whole ? 1 : fa.row_lo, row_hi = whole ? N : fa.row_hi;
+    const CycleWin win = whole ? CycleWin{0, N, 0, N / 2, 1, N / 2} : fa.win;
+    if (POST == 1 && !(row_lo & 1)) return -1;         // see above
+    Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, R);
     g.strips = (N / VecOf<T>::W + OUT - 1) / OUT;
     const long waves = (long)g.strips * g.chunks;
     g.blocks = (int)(((waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
-    const CycleWin win{0, N, 0, N / 2, 1, N / 2};          // a whole grid
     hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout,
                        (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
-                       1, N, g.R, g.strips, g.chunks, c0, c1, fa.zero_in, win);
+                       row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, fa.zero_in, win);
     return g.blocks;
 }
 
@@ -656,15 +663,20 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
     if (parity) std::swap(l.u, l.tmp);
 }
 
-inline int fold_kmax(const mgx_solver* s, int N, int post = 1, bool f64 = true)
+inline int fold_kmax_cfg(const FuseCfg& f, int smoother, int N, int post, bool f64)
 {
-    int k = N >= 8192 ? s->fuse.fold_kmax_big : s->fuse.fold_kmax;
+    int k = N >= 8192 ? f.fold_kmax_big : f.fold_kmax;
     // double Jacobi blocks that end without a residual stage (post-smoothing below the finest
     // level) keep c1 * b in their window and run deeper: one <10,PRE,0> pass instead of two;
     // -38 .. -45 us of the coarse levels of a V(10,10) cycle at 8192^2 on three boxes
     // (4096^2: 200 us against 121 + 98; at 2048^2 the two shallow passes win, 69 against 76 us)
-    if (post == 0 && f64 && N >= 4096 && s->cfg.smoother == MGX_SMOOTHER_JACOBI) k = s->fuse.fold_kmax_nopost;
+    if (post == 0 && f64 && N >= 4096 && smoother == MGX_SMOOTHER_JACOBI) k = f.fold_kmax_nopost;
     return f64 ? k : std::min(k, 8);           // no 10-level folded kernels in float
+}
+
+inline int fold_kmax(const mgx_solver* s, int N, int post = 1, bool f64 = true)
+{
+    return fold_kmax_cfg(s->fuse, s->cfg.smoother, N, post, f64);
 }
 
 // The passes (sweeps per pass) of a folded smoothing block: pre-smoothing = (pre false, post 1),
@@ -1649,6 +1661,115 @@ int mgx_slab_rbgs(const mgx_slab* s, void* u, const void* b, void* tmp, int row_
                   int shrink, int* result_in_tmp, void* stream)
 {
     return slab_smooth(MGX_SMOOTHER_RBGS, s, u, b, tmp, row_lo, row_hi, mu, 1.0, shrink, result_in_tmp, stream);
+}
+
+} // extern "C"
+
+namespace {
+// mu sweeps on a slab with the cycle's transfers folded into the passes (k_jacobi_cycle on the
+// window of rows the slab holds).  Local row numbers in, global ones to the kernel.
+template <typename T, int SM>
+int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int row_hi, int mu, double omega,
+                        const mgx_slab* c, const T* coarse_e, T* coarse_b, int crow_lo, int crow_hi, int restrict_mode,
+                        double* scratch, double* sum_dev, int* result_in_tmp, hipStream_t st)
+{
+    constexpr bool rbgs = (SM == 1);
+    constexpr int per = rbgs ? 2 : 1;
+    const int N = 1 << f->level;
+    const long pitch = level_pitch(f->level, f->dtype);
+    const int first = 1 - f->row0, last = N - f->row0;        // local unknown rows [first, last)
+    const FuseCfg fc = fuse_cfg();
+    const int post = coarse_b ? 1 : (sum_dev ? 2 : 0);
+    int parts[64];
+    const int np = plan_fusion(mu, fold_kmax_cfg(fc, rbgs ? MGX_SMOOTHER_RBGS : MGX_SMOOTHER_JACOBI, N, post, sizeof(T) == 8),
+                               sizeof(T) == 8, parts, rbgs);
+    const T om = (T)omega;
+    const T c0 = (T)(1.0 - (double)om);
+    const T c1 = (T)((double)om / 4.0);
+    FoldArgs fa;
+    fa.restrict_mode = restrict_mode;
+    fa.partial = scratch;
+    fa.win.row_first = std::max(f->row0, 0);
+    fa.win.row_last = std::min(f->row0 + f->rows - 1, N);
+    fa.win.crow_first = 0; fa.win.crow_last = -1; fa.win.emit_lo = 0; fa.win.emit_hi = 0;
+    if (c) {
+        fa.cpitch = level_pitch(c->level, c->dtype);
+        fa.win.crow_first = std::max(c->row0, 0);
+        fa.win.crow_last = std::min(c->row0 + c->rows - 1, N / 2);
+        fa.win.emit_lo = std::max(c->row0 + crow_lo, 1);
+        fa.win.emit_hi = std::min(c->row0 + crow_hi, N / 2);
+        // base pointers moved back so that GLOBAL coarse rows index them (never dereferenced outside the window)
+        if (coarse_e) fa.coarse_e = coarse_e - (long)c->row0 * fa.cpitch;
+        if (coarse_b) fa.coarse_b = coarse_b - (long)c->row0 * fa.cpitch;
+    }
+    const long back = (long)f->row0 * pitch;
+    T* src = u; T* dst = tmp;
+    int done = 0, blocks = 0;
+    for (int p = 0; p < np; ++p) {
+        const int sw = parts[p], K = per * sw;
+        const bool P = coarse_e && p == 0;
+        const int Q = (p == np - 1) ? post : 0;
+        // rows the later passes still consume; the norm stage of the last pass also needs the
+        // result one row beyond its range (it recomputes that row itself, from this pass's output)
+        const int ext = per * (mu - (done + sw)) + ((post == 2 && p != np - 1) ? 1 : 0);
+        const int lo = std::max(row_lo - ext, first), hi = std::min(row_hi + ext, last);
+        if (hi > lo) {
+            const int R = fuse_rows(fc, N, K);
+            if (P || Q) {
+                if (!cycle_k_supported(K, rbgs, sizeof(T) == 8)) return MGX_ERR_INVALID;
+                fa.row_lo = lo + f->row0; fa.row_hi = hi + f->row0;
+                int rc;
+                if (P && Q == 2) rc = launch_cycle<T, 1, 2, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, R, st);
+                else if (P && Q == 1) rc = launch_cycle<T, 1, 1, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, R, st);
+                else if (P) rc = launch_cycle<T, 1, 0, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, R, st);
+                else if (Q == 1) rc = launch_cycle<T, 0, 1, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, R, st);
+                else rc = launch_cycle<T, 0, 2, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, R, st);
+                if (rc < 0) return MGX_ERR_INVALID;
+                if (Q == 2) blocks = rc;
+            } else if (!rbgs && K == 1) {
+                launch_jacobi<T>(src, b, dst, N, pitch, lo, hi, omega, env_int("MGX_ROWS", 0), st);
+            } else if (!launch_fused<T, SM>(K, src, b, dst, N, pitch, lo, hi, c0, c1, first - 1, last, f->row0 & 1, R, st, f->rows)) {
+                return MGX_ERR_INVALID;
+            }
+        }
+        std::swap(src, dst);
+        done += sw;
+    }
+    if (post == 2) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, st, scratch, blocks, sum_dev);
+    if (result_in_tmp) *result_in_tmp = np & 1;
+    return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_HIP;
+}
+
+} // namespace
+
+extern "C" {
+
+int mgx_slab_cycle(const mgx_slab* f, void* u, const void* b, void* tmp, int row_lo, int row_hi, int mu, double omega,
+                   int smoother, const mgx_slab* c, const void* coarse_e, void* coarse_b, int crow_lo, int crow_hi,
+                   int restrict_mode, double* scratch, double* sum_dev, int* result_in_tmp, void* stream)
+{
+    if (slab_check(f) || !u || !b || !tmp || mu < 1 || mu > 64 || row_hi <= row_lo) return MGX_ERR_INVALID;
+    if ((coarse_e || coarse_b) && (slab_check(c) || c->level != f->level - 1 || c->dtype != f->dtype)) return MGX_ERR_INVALID;
+    if (coarse_b && sum_dev) return MGX_ERR_INVALID;
+    if (sum_dev && !scratch) return MGX_ERR_INVALID;
+    if (coarse_b && (crow_lo < 0 || crow_hi > c->rows || crow_hi < crow_lo)) return MGX_ERR_INVALID;
+    const int N = 1 << f->level;
+    if (row_lo < 0 || row_hi > f->rows || row_lo + f->row0 < 1 || row_hi + f->row0 > N) return MGX_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const bool rbgs = (smoother == MGX_SMOOTHER_RBGS);
+    if (f->dtype == MGX_DTYPE_F64)
+        return rbgs ? slab_cycle_t<double, 1>(f, (double*)u, (const double*)b, (double*)tmp, row_lo, row_hi, mu, omega, c,
+                                              (const double*)coarse_e, (double*)coarse_b, crow_lo, crow_hi, restrict_mode,
+                                              scratch, sum_dev, result_in_tmp, st)
+                    : slab_cycle_t<double, 0>(f, (double*)u, (const double*)b, (double*)tmp, row_lo, row_hi, mu, omega, c,
+                                              (const double*)coarse_e, (double*)coarse_b, crow_lo, crow_hi, restrict_mode,
+                                              scratch, sum_dev, result_in_tmp, st);
+    return rbgs ? slab_cycle_t<float, 1>(f, (float*)u, (const float*)b, (float*)tmp, row_lo, row_hi, mu, omega, c,
+                                         (const float*)coarse_e, (float*)coarse_b, crow_lo, crow_hi, restrict_mode, scratch,
+                                         sum_dev, result_in_tmp, st)
+                : slab_cycle_t<float, 0>(f, (float*)u, (const float*)b, (float*)tmp, row_lo, row_hi, mu, omega, c,
+                                         (const float*)coarse_e, (float*)coarse_b, crow_lo, crow_hi, restrict_mode, scratch,
+                                         sum_dev, result_in_tmp, st);
 }
 
 int mgx_slab_restrict(const mgx_slab* f, const void* u, const void* b, const mgx_slab* c, void* cb, void* zero_u,

@@ -91,6 +91,33 @@ class HipSlabOps:
         self._chk(st, "mgx_slab_" + kind)
         return (tmp, u) if flag.value else (u, tmp)
 
+    def cycle(self, kind, level, row0, u, b, tmp, lo, hi, mu, omega, crow0=0, coarse_e=None, coarse_b=None,
+              clo=0, chi=0, mode=0, want_sumsq=False):
+        """mu sweeps on local rows [lo,hi) (deep-halo shrinking) with the transfers folded in
+        (mgx_slab_cycle): input u + P coarse_e, and / or the restricted residual of the result
+        -> coarse_b rows [clo,chi), or sum (b - A u)^2 over [lo,hi).  Returns (result, scratch, sumsq)."""
+        s = self._slab(level, u, row0)
+        ct = coarse_e if coarse_e is not None else coarse_b
+        cs = self._slab(level - 1, ct, crow0) if ct is not None else None
+        out = scratch = None
+        if want_sumsq:
+            key = (level, u.shape[0])
+            if key not in self._scratch:
+                n = int(self.lib.mgx_slab_scratch_doubles(C.byref(s)))
+                self._scratch[key] = torch.zeros(n, dtype=torch.float64, device=self.device)
+            scratch = self._scratch[key]
+            out = torch.zeros(1, dtype=torch.float64, device=self.device)
+        flag = C.c_int(0)
+        st = self.lib.mgx_slab_cycle(C.byref(s), u.data_ptr(), b.data_ptr(), tmp.data_ptr(), lo, hi, mu, float(omega),
+                                     B.SMOOTHER_RBGS if kind == "rbgs" else B.SMOOTHER_JACOBI,
+                                     C.byref(cs) if cs is not None else None,
+                                     coarse_e.data_ptr() if coarse_e is not None else None,
+                                     coarse_b.data_ptr() if coarse_b is not None else None, clo, chi, mode,
+                                     scratch.data_ptr() if scratch is not None else None,
+                                     out.data_ptr() if out is not None else None, C.byref(flag), self._stream())
+        self._chk(st, "mgx_slab_cycle")
+        return ((tmp, u) if flag.value else (u, tmp)) + (out,)
+
     def restrict(self, flevel, frow0, u, b, crow0, cb, czero, clo, chi, mode, fused=True):
         fs = self._slab(flevel, b, frow0)
         cs = self._slab(flevel - 1, cb, crow0)
@@ -175,7 +202,7 @@ class DistMultigrid:
     """V-cycle multigrid with the levels above `cut_level` split into row slabs."""
 
     def __init__(self, ops, coarse, finest_level, cut_level, mu1=10, mu2=10, omega=2.0 / 3.0, smoother="jacobi",
-                 restrict_mode=0, group=None, staged_halo=False):
+                 restrict_mode=0, group=None, staged_halo=False, fold=None):
         self.ops, self.coarse = ops, coarse
         self.Lf, self.Lcut = finest_level, cut_level
         self.mu1, self.mu2, self.omega, self.smoother, self.restrict_mode = mu1, mu2, omega, smoother, restrict_mode
@@ -187,8 +214,19 @@ class DistMultigrid:
             raise ValueError("finest_level must be above cut_level (otherwise use the single-GPU handle)")
         per_sweep = 2 if smoother == "rbgs" else 1
         self.per = per_sweep
-        self.ext_post = per_sweep * mu2               # halo rows the post-smoothing consumes
+        # fold the transfers into the smoother passes (ops.cycle) as the single-GPU handle does:
+        # the restriction rides on the last pre-smoothing pass, the correction on the first
+        # post-smoothing pass, the residual norm on the last one (MGX_DIST_FOLD=0: separate kernels)
+        if fold is None:
+            import os
+            fold = os.environ.get("MGX_DIST_FOLD", "1") != "0"
+        self.fold = bool(fold) and hasattr(ops, "cycle")
+        # halo rows the post-smoothing consumes (+1: the folded norm needs the result one row beyond)
+        self.ext_post = per_sweep * mu2 + (1 if self.fold else 0)
         self.ext_keep = max(self.ext_post, 2)         # rows beyond the owned ones pre-smoothing leaves valid
+        if self.fold:
+            self.ext_keep |= 1                        # the folded restriction wants its range to start on an odd row
+        self._sumsq = None                            # ||r||^2 share produced by the last post-smoothing
         self.ext_coarse = self.ext_post // 2 + 2      # coarse halo rows the extended prolongation reads
         self.halo = max(per_sweep * mu1 + self.ext_keep, self.ext_coarse)
         self.lv = {}
@@ -290,33 +328,71 @@ class DistMultigrid:
         per = C_N // self.P
         return max(self.g * per, 1), min((self.g + 1) * per, C_N)
 
+    def _timed(self, L, mu, lo, hi, fn):
+        """run fn() with device events around it when profiling the finest level"""
+        timed = self.profile and L.level == self.Lf and L.u.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        out = fn()
+        if timed:
+            e1.record()
+            first, last = 1 - L.row0, L.N - L.row0
+            rows = sum(min(hi + self.per * (mu - 1 - k), last) - max(lo - self.per * (mu - 1 - k), first)
+                       for k in range(mu))
+            self._events.append((e0, e1, rows * (L.N - 1) * 3 * L.u.element_size(), mu))
+        if L.level == self.Lf:
+            self.fine_updates += float(mu) * (L.N - 1) * (L.N - 1)
+        return out
+
     def vcycle(self, level=None):
         """PS:575-627 on the slab hierarchy, from `level` (default: finest) down"""
         l = self.Lf if level is None else level
         L = self.lv[l]
-        if self.mu1 > 0:
-            self._smooth(L, self.mu1, self.ext_keep)                                    # PS:581
-        elif L.u_halo < self.ext_keep:
-            self.exchange(L, L.u, L.halo)
-            L.u_halo = L.halo
+        self._sumsq = None
         NC = L.N // 2
         glo, ghi = self._own_coarse_rows(NC)
         plo, phi = self._range(L, self.ext_post)          # fine rows that receive the correction
-        if l - 1 > self.Lcut:
-            Cl = self.lv[l - 1]
-            Cl.u.zero_()                                                                # PS:613
-            self.ops.restrict(l, L.row0, L.u, L.b, Cl.row0, Cl.b, None, glo - Cl.row0, ghi - Cl.row0,
+        to_cut = not (l - 1 > self.Lcut)
+        Cl = None if to_cut else self.lv[l - 1]
+        crow0 = self.c_row0 if to_cut else Cl.row0
+        cb = self.c_own if to_cut else Cl.b
+        fold_pre = self.fold and self.mu1 > 0
+        fold_post = self.fold and self.mu2 > 0
+        # ---- pre-smoothing (PS:581) + residual, restriction, zero coarse guess (PS:604-613) ----
+        if fold_pre:
+            need = self.per * self.mu1 + self.ext_keep
+            if L.u_halo < need:
+                self.exchange(L, L.u, L.halo)
+                L.u_halo = L.halo
+            if Cl is not None:
+                Cl.u.zero_()                                                            # PS:613
+            lo, hi = self._range(L, self.ext_keep)
+            L.u, L.tmp, _ = self._timed(L, self.mu1, lo, hi, lambda: self.ops.cycle(
+                self.smoother, l, L.row0, L.u, L.b, L.tmp, lo, hi, self.mu1, self.omega, crow0=crow0, coarse_b=cb,
+                clo=glo - crow0, chi=ghi - crow0, mode=self.restrict_mode))
+            L.u_halo = self.ext_keep
+        else:
+            if self.mu1 > 0:
+                self._smooth(L, self.mu1, self.ext_keep)                                # PS:581
+            elif L.u_halo < self.ext_keep:
+                self.exchange(L, L.u, L.halo)
+                L.u_halo = L.halo
+            if Cl is not None:
+                Cl.u.zero_()                                                            # PS:613
+            self.ops.restrict(l, L.row0, L.u, L.b, crow0, cb, None, glo - crow0, ghi - crow0,
                               self.restrict_mode, fused=True)                          # PS:604-611
+        # ---- coarse-grid correction (PS:617) ----------------------------------------------------
+        if Cl is not None:
             self.exchange(Cl, Cl.b, Cl.halo)
             Cl.u_halo = Cl.halo                        # zeros are exact halo values
-            self.vcycle(l - 1)                                                          # PS:617
+            self.vcycle(l - 1)
+            self._sumsq = None
             if Cl.u_halo < self.ext_coarse:
                 self.exchange(Cl, Cl.u, self.ext_coarse)
                 Cl.u_halo = self.ext_coarse
-            self.ops.prolong(l, L.row0, L.u, Cl.row0, Cl.u, plo, phi, add=True)         # PS:620-624
+            ce, ce_row0 = Cl.u, Cl.row0
         else:
-            self.ops.restrict(l, L.row0, L.u, L.b, self.c_row0, self.c_own, None, glo - self.c_row0,
-                              ghi - self.c_row0, self.restrict_mode, fused=True)
             if self.P > 1:
                 if self.staged:
                     host = self.c_own.cpu()
@@ -328,19 +404,34 @@ class DistMultigrid:
             else:
                 self.c_b[:NC].copy_(self.c_own)
             self.coarse.vcycle_from_zero(self.c_b, self.c_e)                            # levels cut..coarsest
-            self.ops.prolong(l, L.row0, L.u, 0, self.c_e, plo, phi, add=True)
+            ce, ce_row0 = self.c_e, 0
+        # ---- correction (PS:620-624) + post-smoothing (PS:625) (+ the residual norm) -----------
         L.u_halo = min(L.u_halo, self.ext_post)
-        self._smooth(L, self.mu2, 0)                                                    # PS:625
-        if self.mu2 <= 0:
+        if fold_post:
+            lo, hi = self._range(L, 0)
+            want = (l == self.Lf)
+            L.u, L.tmp, sq = self._timed(L, self.mu2, lo, hi, lambda: self.ops.cycle(
+                self.smoother, l, L.row0, L.u, L.b, L.tmp, lo, hi, self.mu2, self.omega, crow0=ce_row0, coarse_e=ce,
+                want_sumsq=want))
             L.u_halo = 0
+            self._sumsq = sq if want else None
+        else:
+            self.ops.prolong(l, L.row0, L.u, ce_row0, ce, plo, phi, add=True)           # PS:620-624
+            self._smooth(L, self.mu2, 0)                                                # PS:625
+            if self.mu2 <= 0:
+                L.u_halo = 0
 
     def residual_norm(self):
         """||b - A u||_2 on the finest level (all ranks get the value)"""
         L = self.lv[self.Lf]
-        if L.u_halo < 1:
-            self.exchange(L, L.u, L.halo)        # deep enough for the next pre-smoothing too
-            L.u_halo = L.halo
-        s = self.ops.sumsq(self.Lf, L.row0, L.u, L.b, L.upd_lo, L.upd_hi)
+        if self._sumsq is not None:
+            s = self._sumsq                      # produced by the last post-smoothing pass
+            self._sumsq = None
+        else:
+            if L.u_halo < 1:
+                self.exchange(L, L.u, L.halo)    # deep enough for the next pre-smoothing too
+                L.u_halo = L.halo
+            s = self.ops.sumsq(self.Lf, L.row0, L.u, L.b, L.upd_lo, L.upd_hi)
         if self.P > 1:
             if self.staged:
                 h = s.cpu()
@@ -373,6 +464,7 @@ class DistMultigrid:
         interior = ((rows[:, None] >= 1) & (rows[:, None] <= L.N - 1) & (cols[None, :] >= 1) & (cols[None, :] <= L.N - 1))
         t.zero_()
         t[:, : L.N + 1] = torch.where(interior, vals, torch.zeros_like(vals))
+        self._sumsq = None
         if which == "u":
             L.u_halo = L.halo
 

@@ -64,6 +64,29 @@ class CpuSlabOps:
             flip = not flip
         return (tmp, u) if flip else (u, tmp)
 
+    def cycle(self, kind, level, row0, u, b, tmp, lo, hi, mu, omega, crow0=0, coarse_e=None, coarse_b=None,
+              clo=0, chi=0, mode=0, want_sumsq=False):
+        """mgx_slab_cycle composed from the separate operators, and STRICTER than the device about
+        what it leaves behind: every row outside [lo,hi) (the only rows the call promises) is
+        poisoned with NaN, so a driver that relied on anything else would fail the test."""
+        N = 1 << level
+        per = 2 if kind == "rbgs" else 1
+        first, last = 1 - row0, N - row0
+        elo = 1 if want_sumsq else 0                       # the folded norm needs the result one row beyond
+        if coarse_e is not None:                           # the kernel corrects every row it reads
+            self.prolong(level, row0, u, crow0, coarse_e, max(lo - elo - per * mu, first), min(hi + elo + per * mu, last),
+                         add=True)
+        res, scr = self.smooth(kind, level, row0, u, b, tmp, max(lo - elo, first), min(hi + elo, last), mu, omega,
+                               shrink=True)
+        if coarse_b is not None:
+            self.restrict(level, row0, res, b, crow0, coarse_b, None, clo, chi, mode, fused=True)
+        sq = self.sumsq(level, row0, res, b, lo, hi) if want_sumsq else None
+        rows = np.arange(res.shape[0])
+        bad = ((rows < lo) | (rows >= hi)) & (rows + row0 >= 1) & (rows + row0 <= N - 1)
+        for t in (res, scr):
+            t.numpy()[bad, 1:N] = np.nan
+        return res, scr, sq
+
     def restrict(self, flevel, frow0, u, b, crow0, cb, czero, clo, chi, mode, fused=True):
         N = 1 << flevel
         NC = N // 2

@@ -31,7 +31,7 @@ def _worker(rank, world, port, cfg, ret):
         ops = CpuSlabOps(torch.float64)
         coarse = OracleCoarseSolver(po, cfg["cut"], cfg["coarsest"], cfg)
         mg = DistMultigrid(ops, coarse, cfg["finest"], cfg["cut"], mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"],
-                           smoother=cfg["smoother"], restrict_mode=cfg["restrict_mode"])
+                           smoother=cfg["smoother"], restrict_mode=cfg["restrict_mode"], fold=cfg.get("fold", True))
         L = cfg["finest"]
         n = (1 << L) - 1
         b = po.rhs_sine(L)
@@ -71,11 +71,14 @@ BASE = dict(finest=8, cut=6, coarsest=4, mu1=2, mu2=1, omega=2.0 / 3.0, smoother
             max_cycles=6)
 
 
+@pytest.mark.parametrize("fold", [True, False])
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("smoother,mu1,mu2", [("jacobi", 2, 1), ("jacobi", 3, 3), ("rbgs", 1, 1), ("jacobi", 2, 0),
                                               ("jacobi", 0, 2)])
-def test_slab_vcycle_matches_single_process_oracle(po, world, smoother, mu1, mu2):
-    cfg = dict(BASE, smoother=smoother, mu1=mu1, mu2=mu2)
+def test_slab_vcycle_matches_single_process_oracle(po, world, smoother, mu1, mu2, fold):
+    """fold = True: transfers folded into the smoother passes (ops.cycle, the default);
+    False: separate restriction / prolongation / norm operators"""
+    cfg = dict(BASE, smoother=smoother, mu1=mu1, mu2=mu2, fold=fold)
     got = _run(world, cfg)
     u_ref, h_ref = _reference(po, cfg)
     h = np.array(got["hist"])

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _setup(pkg, po, cfg, staged=False):
+def _setup(pkg, po, cfg, staged=False, fold=None):
     import torch
 
     from multigrid_nikhil_c_amd.dist import DistMultigrid, HipCoarseSolver, HipSlabOps
@@ -20,7 +20,8 @@ def _setup(pkg, po, cfg, staged=False):
     dt = torch.float64
     ccfg = dict(mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"], smoother=cfg["smoother"], restrict_mode=0, bottom=0)
     mg = DistMultigrid(HipSlabOps(dt), HipCoarseSolver(cfg["cut"], cfg["coarsest"], ccfg, dt), cfg["finest"], cfg["cut"],
-                       mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"], smoother=cfg["smoother"], staged_halo=staged)
+                       mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"], smoother=cfg["smoother"], staged_halo=staged,
+                       fold=cfg.get("fold", fold))
     L = cfg["finest"]
     n = (1 << L) - 1
     b = po.rhs_sine(L)
@@ -40,9 +41,13 @@ def _single(pkg, cfg, b, u0, cycles):
         return h, mg.get_solution()
 
 
-@pytest.mark.parametrize("smoother,mu1,mu2", [("jacobi", 2, 1), ("jacobi", 10, 10), ("rbgs", 2, 1)])
-def test_world1_slab_driver_equals_single_gpu_solve(pkg, po, smoother, mu1, mu2):
-    cfg = dict(finest=10, cut=8, coarsest=6, mu1=mu1, mu2=mu2, omega=2.0 / 3.0, smoother=smoother)
+@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("smoother,mu1,mu2", [("jacobi", 2, 1), ("jacobi", 10, 10), ("rbgs", 2, 1), ("jacobi", 3, 0),
+                                              ("jacobi", 0, 2), ("rbgs", 1, 3)])
+def test_world1_slab_driver_equals_single_gpu_solve(pkg, po, smoother, mu1, mu2, fold):
+    """fold: the transfers ride on the smoother passes (mgx_slab_cycle, the default) or run as
+    separate slab kernels; either way the same bits as mgx_solve"""
+    cfg = dict(finest=10, cut=8, coarsest=6, mu1=mu1, mu2=mu2, omega=2.0 / 3.0, smoother=smoother, fold=fold)
     mg, b, u0 = _setup(pkg, po, cfg)
     hist = [mg.residual_norm()]
     for _ in range(3):
@@ -83,18 +88,25 @@ def _worker(rank, world, port, cfg, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("smoother,mu1,mu2", [("jacobi", 3, 2), ("rbgs", 1, 1)])
-def test_two_ranks_on_one_gpu_equal_single_gpu_solve(pkg, po, smoother, mu1, mu2):
+@pytest.mark.parametrize("world,smoother,mu1,mu2,fold", [
+    (2, "jacobi", 3, 2, True), (2, "rbgs", 1, 1, True), (2, "jacobi", 10, 10, True), (2, "jacobi", 3, 2, False),
+    # several passes per block with the transfers folded into the first / last one
+    (2, "jacobi", 7, 6, True), (2, "rbgs", 3, 3, True), (2, "jacobi", 10, 10, False),
+    # interior ranks have two slab edges
+    (4, "jacobi", 10, 10, True), (4, "rbgs", 2, 1, True)])
+def test_ranks_sharing_one_gpu_equal_single_gpu_solve(pkg, po, world, smoother, mu1, mu2, fold):
     import torch.multiprocessing as mp
 
-    cfg = dict(finest=9, cut=7, coarsest=5, mu1=mu1, mu2=mu2, omega=2.0 / 3.0, smoother=smoother, cycles=3)
+    big = mu1 >= 7 or world > 2
+    cfg = dict(finest=10 if big else 9, cut=7, coarsest=5, mu1=mu1, mu2=mu2, omega=2.0 / 3.0, smoother=smoother,
+               cycles=3, fold=fold)
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(2, 29700 + os.getpid() % 1000, cfg, ret), nprocs=2, join=True)
-    n = (1 << 9) - 1
-    b, u0 = po.rhs_sine(9), po.fill_uniform((n, n), 12345)
+    mp.spawn(_worker, args=(world, 29700 + os.getpid() % 1000, cfg, ret), nprocs=world, join=True)
+    n = (1 << cfg["finest"]) - 1
+    b, u0 = po.rhs_sine(cfg["finest"]), po.fill_uniform((n, n), 12345)
     h_ref, u_ref = _single(pkg, cfg, b, u0, 3)
     assert np.allclose(ret["hist"], h_ref, rtol=1e-13, atol=0)
-    for r in range(2):
+    for r in range(world):
         lo, hi, own = ret[f"rows{r}"]
         assert np.array_equal(own, u_ref[lo - 1:hi - 1])
 
