@@ -151,7 +151,9 @@ def run(args, emit=None):
                 "workload": f"2D Poisson {1 << L}^2 (n={n} interior), {L - min(args.coarsest, cut) + 1}-level V({args.mu1},{args.mu2}) cycle, "
                             f"{'weighted Jacobi w=%.4f' % args.omega if args.smoother == 'jacobi' else 'red-black Gauss-Seidel'}, "
                             f"{args.dtype}, row slabs over {world} GPUs on levels {cut + 1}..{L} ({mg.halo}-row deep halos, "
-                            f"{'RCCL send/recv' if backend == 'nccl' else backend + ' with host-staged halos (rehearsal)'}), levels <= {cut} replicated, exact bottom solve at {(1 << min(args.coarsest, cut)) - 1}^2",
+                            f"{'RCCL send/recv' if backend == 'nccl' else backend + ' with host-staged halos (rehearsal)'}, "
+                            f"{'transfers folded into the smoother passes' if mg.fold else 'separate transfer kernels'}), "
+                            f"levels <= {cut} replicated, exact bottom solve at {(1 << min(args.coarsest, cut)) - 1}^2",
                 "finest_level": L, "coarsest_level": min(args.coarsest, cut), "cut_level": cut, "mu1": args.mu1,
                 "mu2": args.mu2, "smoother": args.smoother, "step": "one V-cycle + residual norm",
                 "parallelism": f"slab{world}",
@@ -162,8 +164,10 @@ def run(args, emit=None):
             "halo_exchanges_per_step": mg.exchanges_timed / max(args.steps, 1),
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("k_rbgs<%s>" if args.smoother == "rbgs" else "k_jacobi_fused<%s,K> (slab rows, deep halos)")
-                          % ("double" if es == 8 else "float"),
+                "kernel": ("k_jacobi_fused / k_jacobi_cycle<%s,K,PRE,POST,%d> on the slab's row window (deep halos, "
+                           "transfers folded into the passes)" if mg.fold else
+                           "k_jacobi_fused<%s,K,%d> (slab rows, deep halos; separate transfer kernels)")
+                          % ("double" if es == 8 else "float", 1 if args.smoother == "rbgs" else 0),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "how": "rank 0: torch.cuda events (current stream = the kernels' stream) around every finest-level "
