@@ -129,6 +129,11 @@ def lib() -> C.CDLL:
     return L
 
 
+def lib_loaded() -> bool:
+    """has libmgx.so been loaded into this process yet?"""
+    return _lib is not None
+
+
 def default_config(**kw) -> Config:
     c = Config()
     lib().mgx_config_default(C.byref(c))

@@ -54,7 +54,13 @@ class HipSlabOps:
 
     def __init__(self, dtype=torch.float64, device=None):
         if not torch.cuda.is_available():
-            raise B.MgxError("HipSlabOps needs a HIP device (no CPU fallback)")
+            hint = ""
+            if B.lib_loaded():
+                # libmgx links the system ROCm runtime, the torch wheel carries its own: whichever is
+                # loaded first serves both, and torch's CUDA layer only comes up on its own one
+                hint = ("; libmgx.so was loaded before torch in this process - import torch (or this module) "
+                        "before the first libmgx call")
+            raise B.MgxError("HipSlabOps needs a HIP device (no CPU fallback)" + hint)
         self.lib = B.lib()
         self.dtype = dtype
         self.code = B.DTYPE_F64 if dtype == torch.float64 else B.DTYPE_F32

@@ -7,6 +7,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libmgx.so is loaded: see HipSlabOps.__init__ on the two HIP runtimes)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
