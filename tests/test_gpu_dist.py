@@ -18,15 +18,16 @@ def _setup(pkg, po, cfg, staged=False, fold=None):
 
     from multigrid_nikhil_c_amd.dist import DistMultigrid, HipCoarseSolver, HipSlabOps
 
-    dt = torch.float64
+    dt = torch.float32 if cfg.get("dtype") == "f32" else torch.float64
     ccfg = dict(mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"], smoother=cfg["smoother"], restrict_mode=0, bottom=0)
     mg = DistMultigrid(HipSlabOps(dt), HipCoarseSolver(cfg["cut"], cfg["coarsest"], ccfg, dt), cfg["finest"], cfg["cut"],
                        mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"], smoother=cfg["smoother"], staged_halo=staged,
                        fold=cfg.get("fold", fold))
     L = cfg["finest"]
     n = (1 << L) - 1
-    b = po.rhs_sine(L)
-    u0 = po.fill_uniform((n, n), 12345)
+    npdt = np.float32 if dt == torch.float32 else np.float64
+    b = po.rhs_sine(L).astype(npdt)
+    u0 = po.fill_uniform((n, n), 12345).astype(npdt)
     bt, ut = torch.from_numpy(np.pad(b, 1)).cuda(), torch.from_numpy(np.pad(u0, 1)).cuda()
     mg.set_fine("b", lambda r, c, N: bt[r, c])
     mg.set_fine("u", lambda r, c, N: ut[r, c])
@@ -35,7 +36,8 @@ def _setup(pkg, po, cfg, staged=False, fold=None):
 
 def _single(pkg, cfg, b, u0, cycles):
     with pkg.Multigrid(finest_level=cfg["finest"], coarsest_level=cfg["coarsest"], mu1=cfg["mu1"], mu2=cfg["mu2"],
-                       omega=cfg["omega"], smoother=1 if cfg["smoother"] == "rbgs" else 0, schedule=0) as mg:
+                       omega=cfg["omega"], smoother=1 if cfg["smoother"] == "rbgs" else 0, schedule=0,
+                       dtype=0 if cfg.get("dtype") == "f32" else 1) as mg:
         mg.set_rhs(b)
         mg.set_guess(u0)
         st, h = mg.solve(tol=0.0, max_cycles=cycles)
@@ -94,17 +96,22 @@ def _worker(rank, world, port, cfg, ret):
     # several passes per block with the transfers folded into the first / last one
     (2, "jacobi", 7, 6, True), (2, "rbgs", 3, 3, True), (2, "jacobi", 10, 10, False),
     # interior ranks have two slab edges
-    (4, "jacobi", 10, 10, True), (4, "rbgs", 2, 1, True)])
+    (4, "jacobi", 10, 10, True), (4, "rbgs", 2, 1, True),
+    # float slabs (world < 0 marks them)
+    (-2, "jacobi", 10, 10, True), (-2, "rbgs", 2, 2, True), (-2, "jacobi", 4, 3, False)])
 def test_ranks_sharing_one_gpu_equal_single_gpu_solve(pkg, po, world, smoother, mu1, mu2, fold):
     import torch.multiprocessing as mp
 
+    dtype = "f32" if world < 0 else "f64"
+    world = abs(world)
     big = mu1 >= 7 or world > 2
     cfg = dict(finest=10 if big else 9, cut=7, coarsest=5, mu1=mu1, mu2=mu2, omega=2.0 / 3.0, smoother=smoother,
-               cycles=3, fold=fold)
+               cycles=3, fold=fold, dtype=dtype)
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, 29700 + os.getpid() % 1000, cfg, ret), nprocs=world, join=True)
     n = (1 << cfg["finest"]) - 1
-    b, u0 = po.rhs_sine(cfg["finest"]), po.fill_uniform((n, n), 12345)
+    npdt = np.float32 if dtype == "f32" else np.float64
+    b, u0 = po.rhs_sine(cfg["finest"]).astype(npdt), po.fill_uniform((n, n), 12345).astype(npdt)
     h_ref, u_ref = _single(pkg, cfg, b, u0, 3)
     assert np.allclose(ret["hist"], h_ref, rtol=1e-13, atol=0)
     for r in range(world):
