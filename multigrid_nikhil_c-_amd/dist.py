@@ -313,21 +313,9 @@ class DistMultigrid:
             self.exchange(L, L.u, L.halo)
             L.u_halo = L.halo
         lo, hi = self._range(L, keep)
-        timed = self.profile and L.level == self.Lf and L.u.is_cuda
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        L.u, L.tmp = self.ops.smooth(self.smoother, L.level, L.row0, L.u, L.b, L.tmp, lo, hi, mu, self.omega,
-                                     shrink=True)
-        if timed:
-            e1.record()
-            first, last = 1 - L.row0, L.N - L.row0
-            rows = sum(min(hi + self.per * (mu - 1 - k), last) - max(lo - self.per * (mu - 1 - k), first)
-                       for k in range(mu))
-            self._events.append((e0, e1, rows * (L.N - 1) * 3 * L.u.element_size(), mu))
+        L.u, L.tmp = self._timed(L, mu, lo, hi, lambda: self.ops.smooth(
+            self.smoother, L.level, L.row0, L.u, L.b, L.tmp, lo, hi, mu, self.omega, shrink=True))
         L.u_halo = keep
-        if L.level == self.Lf:
-            self.fine_updates += float(mu) * (L.N - 1) * (L.N - 1)
 
     def _own_coarse_rows(self, C_N):
         """coarse unknown rows this rank produces: global [lo, hi)"""
