@@ -121,7 +121,16 @@ def cpu_baseline(args):
     sweeps_csr = 100
     t_csr, _ = po.baseline_jacobi("csr", uc, bc, sweeps_csr, args.omega)
     v_csr = nc * nc * sweeps_csr / t_csr
-    main = {"value": v_omp, "unit": "updates/s", "cores": threads, "kind": "port",
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    host = {"cpu_model": model, "nproc": os.cpu_count(), "threads_usable": threads}
+    main = {"value": v_omp, "unit": "updates/s", "cores": threads, "kind": "port", "host": host,
             "sample": f"{sweeps} weighted-Jacobi sweeps, {n}^2 {args.dtype if args.dtype != 'mixed' else 'f64'} grid, "
                       f"matrix-free OpenMP oracle ({t_omp:.2f} s)"}
     extra = {"value": v_csr, "unit": "updates/s", "cores": 1, "kind": "port",
