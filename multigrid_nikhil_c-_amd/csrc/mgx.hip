@@ -1298,9 +1298,10 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
         const int sw = parts[p], K = per * sw;
         const bool P = coarse_e && p == 0;
         const int Q = (p == np - 1) ? post : 0;
-        // rows the later passes still consume; the norm stage of the last pass also needs the
-        // result one row beyond its range (it recomputes that row itself, from this pass's output)
-        const int ext = per * (mu - (done + sw)) + ((post == 2 && p != np - 1) ? 1 : 0);
+        // rows the later passes still consume; the norm / restriction stage of the last pass also
+        // needs the result one / two rows beyond its range (it recomputes those rows itself, from
+        // this pass's output)
+        const int ext = per * (mu - (done + sw)) + (p != np - 1 ? (post == 2 ? 1 : (post == 1 ? 2 : 0)) : 0);
         const int lo = std::max(row_lo - ext, first), hi = std::min(row_hi + ext, last);
         if (hi > lo) {
             const int R = fuse_rows(fc, N, K);

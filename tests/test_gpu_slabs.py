@@ -140,3 +140,68 @@ def test_slab_argument_validation(pkg):
     assert L.mgx_slab_rbgs(C.byref(s), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 9, 1, 0, C.byref(flag), None) != 0
     assert L.mgx_slab_jacobi(C.byref(s), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 9, 1, 0.6, 0, C.byref(flag), None) == 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("smoother,mu", [("jacobi", 10), ("jacobi", 3), ("rbgs", 3)])
+def test_slab_cycle_equals_the_separate_slab_operators(pkg, po, dt, smoother, mu):
+    """mgx_slab_cycle on an INTERIOR slab (halo rows on both sides, window narrower than the grid)
+    against the oracle's whole-grid operators: correction on load, residual + restriction of
+    the result, and the norm of the result - and its argument checks."""
+    torch = _torch()
+    L = pkg.lib()
+    level = 9
+    N, NC = 1 << level, 1 << (level - 1)
+    code = pkg.DTYPE_F64 if dt == np.float64 else pkg.DTYPE_F32
+    kind = pkg.SMOOTHER_RBGS if smoother == "rbgs" else pkg.SMOOTHER_JACOBI
+    per = 2 if smoother == "rbgs" else 1
+    rng = np.random.default_rng(21)
+    v = rng.uniform(-1, 1, (N - 1, N - 1)).astype(dt)
+    f = rng.uniform(-1, 1, (N - 1, N - 1)).astype(dt)
+    e = rng.uniform(-1, 1, (NC - 1, NC - 1)).astype(dt)
+    sm = po.rbgs if smoother == "rbgs" else po.jacobi
+    own_lo, own_hi = 128, 256                      # owned fine rows [128, 256): an interior slab
+    halo = per * mu + 4
+    lo, hi = own_lo - halo, own_hi + halo
+    clo, chi = lo // 2 - 1, hi // 2 + 2            # coarse rows the slab holds
+    U, B = grid_from_interior(pkg, v, level, dt), grid_from_interior(pkg, f, level, dt)
+    E = grid_from_interior(pkg, e, level - 1, dt)
+    fs = pkg.Slab(level=level, dtype=code, rows=hi - lo, row0=lo)
+    cs = pkg.Slab(level=level - 1, dtype=code, rows=chi - clo, row0=clo)
+    scratch = torch.zeros(int(L.mgx_slab_scratch_doubles(C.byref(fs))), dtype=torch.float64, device="cuda")
+
+    def run(pre, post, rl, rh):
+        u, b, tmp = U[lo:hi].clone(), B[lo:hi].clone(), torch.zeros_like(U[lo:hi])
+        ce = E[clo:chi].clone()
+        cb = torch.zeros_like(ce)
+        out = torch.zeros(1, dtype=torch.float64, device="cuda")
+        flag = C.c_int()
+        st = L.mgx_slab_cycle(C.byref(fs), u.data_ptr(), b.data_ptr(), tmp.data_ptr(), rl - lo, rh - lo, mu, 2.0 / 3.0, kind,
+                              C.byref(cs), ce.data_ptr() if pre else None, cb.data_ptr() if post == 1 else None,
+                              own_lo // 2 - clo, own_hi // 2 - clo, 0, scratch.data_ptr() if post == 2 else None,
+                              out.data_ptr() if post == 2 else None, C.byref(flag), None)
+        torch.cuda.synchronize()
+        return st, (tmp if flag.value else u).cpu().numpy(), cb.cpu().numpy(), float(out.item())
+
+    # PRE: smooth(v + P e) on the owned rows
+    st, got, _, _ = run(True, 0, own_lo, own_hi)
+    assert st == 0
+    ref = sm(po.prolong_add(v, e), f, mu)
+    assert np.array_equal(got[own_lo - lo:own_hi - lo, 1:N], ref[own_lo - 1:own_hi - 1])
+    # POST 1: restricted residual of the result on the owned coarse rows (range must start on an odd row)
+    st, got, cb, _ = run(False, 1, own_lo - 1, own_hi + 1)
+    assert st == 0
+    ref = sm(v, f, mu)
+    assert np.array_equal(got[own_lo - 1 - lo:own_hi + 1 - lo, 1:N], ref[own_lo - 2:own_hi])
+    rr = po.restrict(po.residual(ref, f))
+    assert np.array_equal(cb[own_lo // 2 - clo:own_hi // 2 - clo, 1:NC], rr[own_lo // 2 - 1:own_hi // 2 - 1])
+    assert np.all(cb[:own_lo // 2 - clo] == 0) and np.all(cb[own_hi // 2 - clo:] == 0)      # nothing outside the rows asked for
+    st, *_ = run(False, 1, own_lo, own_hi)
+    assert st != 0                                   # an even first row cannot carry the folded restriction
+    # POST 2: sum of squares of the residual of the result over the owned rows
+    st, got, _, sq = run(True, 2, own_lo, own_hi)
+    assert st == 0
+    ref = sm(po.prolong_add(v, e), f, mu)
+    r = po.residual(ref, f)[own_lo - 1:own_hi - 1].astype(np.float64)
+    assert abs(sq - float(np.sum(r * r))) <= 1e-12 * float(np.sum(r * r))
+    assert np.array_equal(got[own_lo - lo:own_hi - lo, 1:N], ref[own_lo - 1:own_hi - 1])
