@@ -1302,7 +1302,8 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
         // needs the result one / two rows beyond its range (it recomputes those rows itself, from
         // this pass's output)
         const int ext = per * (mu - (done + sw)) + (p != np - 1 ? (post == 2 ? 1 : (post == 1 ? 2 : 0)) : 0);
-        const int lo = std::max(row_lo - ext, first), hi = std::min(row_hi + ext, last);
+        // never beyond the unknown rows, never outside the slab (rows are written on [lo, hi))
+        const int lo = std::max(std::max(row_lo - ext, first), 0), hi = std::min(std::min(row_hi + ext, last), f->rows);
         if (hi > lo) {
             const int R = fuse_rows(fc, N, K);
             if (P || Q) {
