@@ -528,7 +528,7 @@ int enqueue_norm(mgx_solver* s, const Level& l, const void* u, const void* b, in
     if (s->norm_blocks_ready > 0 && u == s->lv[s->cfg.finest_level].u && !s->mixed) {
         // the last post-smoothing pass already summed (b - A u)^2 per block
         Prof p(s, cls, 1);
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, s->stream, s->partial, s->norm_blocks_ready,
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kReduceThreads), 0, s->stream, s->partial, s->norm_blocks_ready,
                            s->sum_dev);
     } else {
         Prof p(s, cls, 2);
@@ -1125,7 +1125,7 @@ int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double
                     hipLaunchKernelGGL(k_update_residual, dim3(gr.blocks), dim3(kBlock), 0, s->stream, (const double*)d.u,
                                        (const float*)w.u, (const double*)d.b, (double*)d.tmp, (float*)w.b, pending_scale,
                                        1.0 / next_scale, s->partial, d.N, d.pitch, w.pitch, 1, d.N, gr.R, gr.strips, gr.chunks);
-                    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, s->stream, s->partial, gr.blocks, s->sum_dev);
+                    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kReduceThreads), 0, s->stream, s->partial, gr.blocks, s->sum_dev);
                     std::swap(d.u, d.tmp);
                 } else {
                     launch_residual<double, 2>((const double*)d.u, (const double*)d.b, w.b, w.pitch, s->partial,
@@ -1326,7 +1326,7 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
         std::swap(src, dst);
         done += sw;
     }
-    if (post == 2) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, st, scratch, blocks, sum_dev);
+    if (post == 2) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kReduceThreads), 0, st, scratch, blocks, sum_dev);
     if (result_in_tmp) *result_in_tmp = np & 1;
     return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_HIP;
 }

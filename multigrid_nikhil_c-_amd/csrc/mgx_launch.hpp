@@ -423,7 +423,7 @@ void launch_residual(const T* v, const T* b, void* out, long pitch_out, double* 
     hipLaunchKernelGGL((k_residual<T, MODE>), dim3(g.blocks), dim3(kBlock), 0, st, v, b, out, pitch_out, partial,
                        inv_scale, N, pitch, row_lo, row_hi, g.R, g.strips, g.chunks);
     if (MODE != 0)
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, st, partial, g.blocks, sum_dev);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kReduceThreads), 0, st, partial, g.blocks, sum_dev);
 }
 
 } // namespace mgx

@@ -320,7 +320,7 @@ void run_level(int level, int iters)
         CK(hipMalloc(&partial, (g.blocks + 8) * sizeof(double))); CK(hipMalloc(&sum, 8));
         float ms = tm.run([&] {
             hipLaunchKernelGGL((k_residual<T, 1>), dim3(g.blocks), dim3(kBlock), 0, 0, u, b, (void*)nullptr, 0L, partial, 1.0, N, pitch, 1, N, g.R, g.strips, g.chunks);
-            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, 0, partial, g.blocks, sum);
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kReduceThreads), 0, 0, partial, g.blocks, sum);
         }, 3, iters);
         report("residual norm (2 launches)", ms, 2.0 * sizeof(T));
         CK(hipFree(partial)); CK(hipFree(sum));
