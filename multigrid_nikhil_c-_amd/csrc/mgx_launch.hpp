@@ -106,12 +106,16 @@ bool launch_fused(int K, const T* vin, const T* b, T* vout, int N, long pitch, i
     return false;
 }
 
-// chunk height of a fused pass: shallow passes (K <= 3 levels) want many short
-// chunks, deep ones want tall chunks to amortise their 2K redundant rows (measured)
+// chunk height of a fused pass: a chunk recomputes 2K halo rows, so the deeper the pass the
+// taller the chunk, against the parallelism short chunks give (all measured, bench.py sweeps
+// of MGX_FUSE_ROWS): K <= 2: 8 rows (flat from 8 to 24); K = 3, 4: 16-24 rows (8192^2 RB-GS
+// V(2,2) 1.52 -> 1.32 ms, Jacobi V(4,3) 1.45 -> 1.27 ms against 8 rows; 4-7 % at 4096^2 and
+// 2048^2); K >= 5: N/128 clamped to [8, 64] (flat between 48 and 96 at 8192^2)
 inline int fuse_rows(const FuseCfg& fc, int N, int K)
 {
     if (fc.rows > 0) return fc.rows;
-    if (K <= 4) return 8;
+    if (K <= 2) return 8;
+    if (K <= 4) return N >= 8192 ? 24 : 16;
     int R = N / 128;
     if (R < 8) R = 8;
     if (R > 64) R = 64;
