@@ -339,7 +339,7 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
         const bool P = pre && first;
         const int Q = last ? post : 0;
         const int K = per * parts[p];
-        const int R = fuse_rows(s->fuse, l.N, K);
+        const int R = fuse_rows(s->fuse, l.N, K, sizeof(T) == 8);
         fa.zero_in = (first && zero_in) ? 1 : 0;
         int blocks = 0;
         if (P && Q == 2) blocks = launch_cycle<T, 1, 2, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
@@ -1305,7 +1305,7 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
         // never beyond the unknown rows, never outside the slab (rows are written on [lo, hi))
         const int lo = std::max(std::max(row_lo - ext, first), 0), hi = std::min(std::min(row_hi + ext, last), f->rows);
         if (hi > lo) {
-            const int R = fuse_rows(fc, N, K);
+            const int R = fuse_rows(fc, N, K, sizeof(T) == 8);
             if (P || Q) {
                 if (!cycle_k_supported(K, rbgs, sizeof(T) == 8)) return MGX_ERR_INVALID;
                 fa.row_lo = lo + f->row0; fa.row_hi = hi + f->row0;

@@ -110,15 +110,17 @@ bool launch_fused(int K, const T* vin, const T* b, T* vout, int N, long pitch, i
 // taller the chunk, against the parallelism short chunks give (all measured, bench.py sweeps
 // of MGX_FUSE_ROWS): K <= 2: 8 rows (flat from 8 to 24); K = 3, 4: 16-24 rows (8192^2 RB-GS
 // V(2,2) 1.52 -> 1.32 ms, Jacobi V(4,3) 1.45 -> 1.27 ms against 8 rows; 4-7 % at 4096^2 and
-// 2048^2); K >= 5: N/128 clamped to [8, 64] (flat between 48 and 96 at 8192^2)
-inline int fuse_rows(const FuseCfg& fc, int N, int K)
+// 2048^2); K >= 5: N/128 clamped to [8, 64] in double (flat between 48 and 96 at 8192^2), to
+// [8, 32] in float (a float wave covers twice the columns, so a grid has half the strips:
+// 8192^2 fp32 V(10,10) finest level 0.96 -> 0.90 ms at 32 rows)
+inline int fuse_rows(const FuseCfg& fc, int N, int K, bool f64 = true)
 {
     if (fc.rows > 0) return fc.rows;
     if (K <= 2) return 8;
     if (K <= 4) return N >= 8192 ? 24 : 16;
     int R = N / 128;
     if (R < 8) R = 8;
-    if (R > 64) R = 64;
+    if (R > (f64 ? 64 : 32)) R = f64 ? 64 : 32;
     return R;
 }
 
@@ -242,7 +244,7 @@ int smooth_block(int smoother, T* a, const T* rhs, T* b2, int N, long pitch, int
             } else if (rbgs && !allow_fuse) {
                 launch_rbgs<T>(src, rhs, dst, N, pitch, lo, hi, row_parity, bl, bh, rpc, st);
             } else {
-                const int R = fuse_rows(fc, N, K);
+                const int R = fuse_rows(fc, N, K, sizeof(T) == 8);
                 const bool ok = rbgs ? launch_fused<T, 1>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st, rows_alloc)
                                      : launch_fused<T, 0>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st, rows_alloc);
                 if (!ok) return MGX_ERR_INVALID;

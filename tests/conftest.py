@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+try:
+    # before libmgx.so is ever loaded: the torch wheel and libmgx bring a HIP runtime each, the one
+    # loaded first serves both, and torch's device layer only comes up on its own
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional for the single-GPU tests
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
