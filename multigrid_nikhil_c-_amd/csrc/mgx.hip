@@ -252,9 +252,14 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
     if (parity) std::swap(l.u, l.tmp);
 }
 
-inline int fold_kmax_cfg(const FuseCfg& f, int smoother, int N, int post, bool f64)
+inline int fold_kmax_cfg(const FuseCfg& f, int smoother, int N, int post, bool f64, int mu)
 {
     int k = N >= 8192 ? f.fold_kmax_big : f.fold_kmax;
+    // A block of up to 8 sweeps is ONE pass: a 6- or 8-level folded pass costs 1.15 / 1.6 x a
+    // 5-level one, two shallow passes cost 2 x (8192^2 V(6,6) 2.17 -> 1.50 ms, V(8,8) 2.29 -> 1.96 ms
+    // per cycle; the same in float and at 4096^2).  From 9 sweeps on, 5-level passes: [5,5] beats
+    // [10] (VALU-bound, 2.2 x) and ties with [8,2].
+    if (mu <= 8 && env_int("MGX_FOLD_SINGLE", 1)) k = std::max(k, 8);
     // double Jacobi blocks that end without a residual stage (post-smoothing below the finest
     // level) keep c1 * b in their window and run deeper: one <10,PRE,0> pass instead of two;
     // -38 .. -45 us of the coarse levels of a V(10,10) cycle at 8192^2 on three boxes
@@ -266,9 +271,9 @@ inline int fold_kmax_cfg(const FuseCfg& f, int smoother, int N, int post, bool f
     return f64 ? k : std::min(k, 8);           // no 10-level folded kernels in float
 }
 
-inline int fold_kmax(const mgx_solver* s, int N, int post = 1, bool f64 = true)
+inline int fold_kmax(const mgx_solver* s, int N, int post, bool f64, int mu)
 {
-    return fold_kmax_cfg(s->fuse, s->cfg.smoother, N, post, f64);
+    return fold_kmax_cfg(s->fuse, s->cfg.smoother, N, post, f64, mu);
 }
 
 // The passes (sweeps per pass) of a folded smoothing block: pre-smoothing = (pre false, post 1),
@@ -297,7 +302,7 @@ int fold_plan(const mgx_solver* s, const Level& l, int mu, bool pre, int post, i
             return nf;
         }
     }
-    return plan_fusion(mu, fold_kmax(s, l.N, post, l.f64), l.f64, parts, rbgs);
+    return plan_fusion(mu, fold_kmax(s, l.N, post, l.f64, mu), l.f64, parts, rbgs);
 }
 
 // mu Jacobi sweeps on a whole level with the prolongation+correction applied while
@@ -1273,7 +1278,7 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
     const FuseCfg fc = fuse_cfg();
     const int post = coarse_b ? 1 : (sum_dev ? 2 : 0);
     int parts[64];
-    const int np = plan_fusion(mu, fold_kmax_cfg(fc, rbgs ? MGX_SMOOTHER_RBGS : MGX_SMOOTHER_JACOBI, N, post, sizeof(T) == 8),
+    const int np = plan_fusion(mu, fold_kmax_cfg(fc, rbgs ? MGX_SMOOTHER_RBGS : MGX_SMOOTHER_JACOBI, N, post, sizeof(T) == 8, mu),
                                sizeof(T) == 8, parts, rbgs);
     const T om = (T)omega;
     const T c0 = (T)(1.0 - (double)om);
@@ -1305,8 +1310,10 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
         // needs the result one / two rows beyond its range (it recomputes those rows itself, from
         // this pass's output)
         const int ext = per * (mu - (done + sw)) + (p != np - 1 ? (post == 2 ? 1 : (post == 1 ? 2 : 0)) : 0);
-        // never beyond the unknown rows, never outside the slab (rows are written on [lo, hi))
-        const int lo = std::max(std::max(row_lo - ext, first), 0), hi = std::min(std::min(row_hi + ext, last), f->rows);
+        // never beyond the unknown rows, and never the slab's first or last row unless it is a global
+        // boundary's neighbour: a row is updated from the rows above and below it, and the single-sweep
+        // kernel (k_jacobi_rows) reads them without asking whether they exist
+        const int lo = std::max(std::max(row_lo - ext, first), 1), hi = std::min(std::min(row_hi + ext, last), f->rows - 1);
         if (hi > lo) {
             const int R = fuse_rows(fc, N, K, sizeof(T) == 8);
             if (P || Q) {
