@@ -94,7 +94,8 @@ def _worker(rank, world, port, cfg, ret):
 @pytest.mark.parametrize("world,smoother,mu1,mu2,fold", [
     (2, "jacobi", 3, 2, True), (2, "rbgs", 1, 1, True), (2, "jacobi", 10, 10, True), (2, "jacobi", 3, 2, False),
     # several passes per block with the transfers folded into the first / last one
-    (2, "jacobi", 7, 6, True), (2, "rbgs", 3, 3, True), (2, "jacobi", 10, 10, False),
+    (2, "jacobi", 7, 6, True), (2, "rbgs", 3, 3, True), (2, "jacobi", 10, 10, False), (2, "jacobi", 8, 9, True),
+    (2, "jacobi", 6, 7, True), (2, "rbgs", 4, 5, True),
     # interior ranks have two slab edges
     (4, "jacobi", 10, 10, True), (4, "rbgs", 2, 1, True),
     # float slabs (world < 0 marks them)

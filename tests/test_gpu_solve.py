@@ -194,7 +194,7 @@ def test_config1_parameters_at_8192_jacobi_v1010(pkg):
 
 @pytest.mark.parametrize("tiles", ["tiles", "marching"])
 @pytest.mark.parametrize("dtype", [1, 0])
-@pytest.mark.parametrize("mu1,mu2", [(10, 10), (2, 1), (1, 1), (5, 3), (3, 0), (6, 8)])
+@pytest.mark.parametrize("mu1,mu2", [(10, 10), (2, 1), (1, 1), (5, 3), (3, 0), (6, 8), (7, 7), (9, 8), (8, 1), (12, 11)])
 def test_folded_cycle_passes_are_bit_identical(pkg, po, monkeypatch, dtype, mu1, mu2, tiles):
     """k_jacobi_cycle / k_tile_smooth (correction on load, residual+restriction and ||r||^2
     appended to the smoother passes) must give the bits of the stand-alone kernels, and both
