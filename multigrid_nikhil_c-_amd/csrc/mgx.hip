@@ -56,7 +56,7 @@ struct mgx_solver {
     double* sum_host = nullptr;     // pinned
     std::string err;
     int rows_per_chunk = 0;         // 0 = auto (MGX_ROWS env overrides)
-    FuseCfg fuse{10, 0, 256, 5, 5, 1024, 10, 10};   // temporal fusion knobs (MGX_FUSE, MGX_FUSE_ROWS, MGX_FUSE_MIN_N, MGX_FOLD_KMAX[_BIG])
+    FuseCfg fuse{10, 0, 256, 10, 10, 1024, 10, 10};   // temporal fusion knobs (MGX_FUSE, MGX_FUSE_ROWS, MGX_FUSE_MIN_N, MGX_FOLD_KMAX[_BIG])
     // profiling
     std::vector<EventPair> ev_used, ev_free;
     double prof_ms[MGX_PROF_COUNT] = {0};
@@ -252,28 +252,57 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
     if (parity) std::swap(l.u, l.tmp);
 }
 
-inline int fold_kmax_cfg(const FuseCfg& f, int smoother, int N, int post, bool f64, int mu)
+// ---- planning the passes of a folded smoothing block ------------------------------------------
+// A folded pass of up to 5 levels is HBM-bound and costs about the same whatever its depth
+// (370-420 us at 8192^2 in double); deeper ones are VALU-bound.  Costs relative to a 5-level
+// pass, from bench.py runs with explicit plans (MGX_PLAN_PRE / MGX_PLAN_POST) and depth caps, in
+// one process each: double 6 levels 1.15, 8 levels 1.63, 10 levels 2.3 (1.8 for the passes
+// without a residual stage from 4096^2 up, which keep c1*b in their window); float 6: 1.34,
+// 8: 1.53; red-black Gauss-Seidel (levels = 2 x sweeps) 6: 1.1, 8: 1.3.  Minimising the sum
+// reproduces every measured optimum: V(6,6) and V(8,8) one pass per block (2.17 -> 1.50 and
+// 2.29 -> 1.96 ms per cycle against [3,3] / [4,4]), V(10,10) [5,5] (against [10] +4 %, [8,2] +2 %),
+// V(12,12) [6,6] (2.69 against 3.31 ms as [5,5,2]), V(9,9) [5,4], RB-GS V(4,4) one pass (1.74
+// against 2.31 ms).  kcap: MGX_FOLD_KMAX / _BIG / _NOPOST / _GS still cap the depth.
+inline int fold_kcap(const FuseCfg& f, int smoother, int N, int post, bool f64)
 {
     int k = N >= 8192 ? f.fold_kmax_big : f.fold_kmax;
-    // A block of up to 8 sweeps is ONE pass: a 6- or 8-level folded pass costs 1.15 / 1.6 x a
-    // 5-level one, two shallow passes cost 2 x (8192^2 V(6,6) 2.17 -> 1.50 ms, V(8,8) 2.29 -> 1.96 ms
-    // per cycle; the same in float and at 4096^2).  From 9 sweeps on, 5-level passes: [5,5] beats
-    // [10] (VALU-bound, 2.2 x) and ties with [8,2].
-    if (mu <= 8 && env_int("MGX_FOLD_SINGLE", 1)) k = std::max(k, 8);
-    // double Jacobi blocks that end without a residual stage (post-smoothing below the finest
-    // level) keep c1 * b in their window and run deeper: one <10,PRE,0> pass instead of two;
-    // -38 .. -45 us of the coarse levels of a V(10,10) cycle at 8192^2 on three boxes
-    // (4096^2: 200 us against 121 + 98; at 2048^2 the two shallow passes win, 69 against 76 us)
-    if (post == 0 && f64 && N >= 4096 && smoother == MGX_SMOOTHER_JACOBI) k = f.fold_kmax_nopost;
-    // red-black Gauss-Seidel levels are cheaper (5 flops, half the points change): passes of 8
-    // levels = 4 sweeps pay off (8192^2 V(4,4): 2.31 -> 1.74 ms per cycle against two passes of 4)
-    if (smoother == MGX_SMOOTHER_RBGS) k = std::max(k, env_int("MGX_FOLD_KMAX_GS", 8));
+    if (post == 0) k = std::min(k, f.fold_kmax_nopost);
+    if (smoother == MGX_SMOOTHER_RBGS) k = std::min(k, env_int("MGX_FOLD_KMAX_GS", 10));
     return f64 ? k : std::min(k, 8);           // no 10-level folded kernels in float
 }
 
-inline int fold_kmax(const mgx_solver* s, int N, int post, bool f64, int mu)
+inline double fold_pass_cost(int K, int smoother, int N, int post, bool f64)
 {
-    return fold_kmax_cfg(s->fuse, s->cfg.smoother, N, post, f64, mu);
+    const bool rbgs = (smoother == MGX_SMOOTHER_RBGS);
+    if (!cycle_k_supported(K, rbgs, f64)) return -1.0;
+    if (rbgs) return K <= 4 ? 1.0 : (K == 6 ? 1.1 : (K == 8 ? 1.3 : 2.4));
+    if (K <= 5) return 1.0;
+    if (!f64) return K == 6 ? 1.34 : 1.53;
+    if (K == 6) return 1.15;
+    if (K == 8) return 1.63;
+    return (post == 0 && N >= 4096) ? 1.8 : 2.3;
+}
+
+// parts[] = sweeps per pass, deepest first (the last pass carries the residual stage, which is
+// what gets expensive with depth; a leading single sweep could not synthesise a zero input)
+inline int plan_folded(const FuseCfg& f, int smoother, int N, int mu, int post, bool f64, int* parts)
+{
+    const int per = (smoother == MGX_SMOOTHER_RBGS) ? 2 : 1;
+    const int smax = std::max(1, fold_kcap(f, smoother, N, post, f64) / per);
+    std::vector<double> best(mu + 1, 1e300);
+    std::vector<int> pick(mu + 1, 1);
+    best[0] = 0.0;
+    for (int m = 1; m <= mu; ++m)
+        for (int k = 1; k <= std::min(m, smax); ++k) {
+            const double c = fold_pass_cost(per * k, smoother, N, post, f64);
+            if (c < 0.0) continue;
+            const double t = best[m - k] + c + 1e-3;      // equal sums: fewer passes
+            if (t < best[m] - 1e-12) { best[m] = t; pick[m] = k; }
+        }
+    int n = 0;
+    for (int m = mu; m > 0; m -= pick[m]) parts[n++] = pick[m];
+    std::sort(parts, parts + n, [](int a, int b) { return a > b; });
+    return n;
 }
 
 // The passes (sweeps per pass) of a folded smoothing block: pre-smoothing = (pre false, post 1),
@@ -302,7 +331,7 @@ int fold_plan(const mgx_solver* s, const Level& l, int mu, bool pre, int post, i
             return nf;
         }
     }
-    return plan_fusion(mu, fold_kmax(s, l.N, post, l.f64, mu), l.f64, parts, rbgs);
+    return plan_folded(f, s->cfg.smoother, l.N, mu, post, l.f64, parts);
 }
 
 // mu Jacobi sweeps on a whole level with the prolongation+correction applied while
@@ -1278,8 +1307,7 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
     const FuseCfg fc = fuse_cfg();
     const int post = coarse_b ? 1 : (sum_dev ? 2 : 0);
     int parts[64];
-    const int np = plan_fusion(mu, fold_kmax_cfg(fc, rbgs ? MGX_SMOOTHER_RBGS : MGX_SMOOTHER_JACOBI, N, post, sizeof(T) == 8, mu),
-                               sizeof(T) == 8, parts, rbgs);
+    const int np = plan_folded(fc, rbgs ? MGX_SMOOTHER_RBGS : MGX_SMOOTHER_JACOBI, N, mu, post, sizeof(T) == 8, parts);
     const T om = (T)omega;
     const T c0 = (T)(1.0 - (double)om);
     const T c1 = (T)((double)om / 4.0);

@@ -138,11 +138,11 @@ inline FuseCfg fuse_cfg()
     // transfer state, so their sweet spot is shallower than the plain fused kernel's and
     // flat: measured in one process on one MI355X, V(10,10) at 8192^2 fp64 takes 2.63 ms as
     // [5,5] and 2.62 as [10] (244-256 VGPRs, 2 waves/SIMD); [5,5] is better on smaller grids.
-    f.fold_kmax = std::max(1, std::min(f.kmax, env_int("MGX_FOLD_KMAX", 5)));
+    f.fold_kmax = std::max(1, std::min(f.kmax, env_int("MGX_FOLD_KMAX", 10)));
     // The same for grids with N >= 8192 (separate knob): there the deep variant [10] is
     // device-dependent - 1.55 vs 1.62 ms for the finest level on one MI355X, 1.87 vs 1.50 ms on
     // another (VALU-bound passes follow the clock the chip holds; the HBM-bound [5,5] does not).
-    f.fold_kmax_big = std::max(1, std::min(f.kmax, env_int("MGX_FOLD_KMAX_BIG", 5)));
+    f.fold_kmax_big = std::max(1, std::min(f.kmax, env_int("MGX_FOLD_KMAX_BIG", 10)));
     // Whole levels up to this N (= 2^L) are smoothed by the LDS tile kernel, all sweeps of a
     // block (up to tile_k levels) per launch; 0 disables it.
     f.tile_max_n = std::max(0, env_int("MGX_TILE_MAX_N", 1024));
