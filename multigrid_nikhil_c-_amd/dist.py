@@ -19,11 +19,12 @@ Communication plan (halo messages are latency-bound, so send few):
     rows plus the rows the restriction (2) and the post-smoothing (mu2) will
     need, and the correction is prolongated onto that extended range as well,
     so neither the restriction nor the post-smoothing needs an exchange.
-  * what is left per cycle: ONE exchange of u on the finest level (it serves the
-    residual norm and the next pre-smoothing), and per distributed coarse level
-    one exchange of the restricted right-hand side and one shallow exchange of
-    the correction before it is prolongated (coarse guesses are zero, halos
-    included, so they need none).
+  * deep correction halos: every level below the finest leaves its post-smoothed correction
+    valid as far into its halos as the level above reads it when prolongating, so the
+    correction is never exchanged either.
+  * what is left per cycle: ONE exchange of u on the finest level (it serves the next
+    pre-smoothing), and ONE exchange per further distributed level, of the restricted
+    right-hand side (coarse guesses are zero, halos included, so they need none).
   * one all_gather of the restricted residual at the cut-over level, one
     all_reduce of a double for ||r||^2.
 
@@ -208,7 +209,7 @@ class DistMultigrid:
     """V-cycle multigrid with the levels above `cut_level` split into row slabs."""
 
     def __init__(self, ops, coarse, finest_level, cut_level, mu1=10, mu2=10, omega=2.0 / 3.0, smoother="jacobi",
-                 restrict_mode=0, group=None, staged_halo=False, fold=None):
+                 restrict_mode=0, group=None, staged_halo=False, fold=None, deep=None):
         self.ops, self.coarse = ops, coarse
         self.Lf, self.Lcut = finest_level, cut_level
         self.mu1, self.mu2, self.omega, self.smoother, self.restrict_mode = mu1, mu2, omega, smoother, restrict_mode
@@ -227,25 +228,42 @@ class DistMultigrid:
             import os
             fold = os.environ.get("MGX_DIST_FOLD", "1") != "0"
         self.fold = bool(fold) and hasattr(ops, "cycle")
-        # halo rows the post-smoothing consumes (+1: the folded norm needs the result one row beyond)
-        self.ext_post = per_sweep * mu2 + (1 if self.fold else 0)
-        self.ext_keep = max(self.ext_post, 2)         # rows beyond the owned ones pre-smoothing leaves valid
-        if self.fold:
-            self.ext_keep |= 1                        # the folded restriction wants its range to start on an odd row
         self._sumsq = None                            # ||r||^2 share produced by the last post-smoothing
-        self.ext_coarse = self.ext_post // 2 + 2      # coarse halo rows the extended prolongation reads
-        self.halo = max(per_sweep * mu1 + self.ext_keep, self.ext_coarse)
+        # Halo plan per level, from the finest level down.  keep_post: rows beyond the owned ones the
+        # post-smoothing leaves valid - 0 on the finest level; on every level below, as many as the
+        # level above reads when it prolongates the correction (ext_coarse), so that the correction
+        # needs NO exchange (deep = False: it is exchanged, and keep_post is 0 everywhere).
+        if deep is None:
+            import os
+            deep = os.environ.get("MGX_DIST_DEEP", "1") != "0"
+        self.deep = bool(deep)
+        self.keep_post, self.ext_post, self.ext_keep, self.ext_coarse, self.halo_of = {}, {}, {}, {}, {}
+        kp = 0
+        for l in range(finest_level, cut_level, -1):
+            self.keep_post[l] = kp
+            # halo rows the post-smoothing consumes (+1 on the finest level: the folded norm needs
+            # the result one row beyond the owned rows)
+            ep = per_sweep * mu2 + kp + (1 if (self.fold and l == finest_level) else 0)
+            ek = max(ep, 2)                           # rows beyond the owned ones pre-smoothing leaves valid
+            if self.fold:
+                ek |= 1                               # the folded restriction wants its range to start on an odd row
+            ec = ep // 2 + 2                          # coarse halo rows the extended prolongation reads
+            self.ext_post[l], self.ext_keep[l], self.ext_coarse[l] = ep, ek, ec
+            self.halo_of[l] = max(per_sweep * mu1 + ek, ec, kp)
+            kp = ec if self.deep else 0
+        self.halo = self.halo_of[finest_level]
         self.lv = {}
         for l in range(cut_level + 1, finest_level + 1):
             N = 1 << l
-            if N % self.P or N // self.P < self.halo:
-                raise ValueError(f"level {l}: {N} rows cannot be split over {self.P} ranks with a {self.halo}-row halo; "
+            halo = self.halo_of[l]
+            if N % self.P or N // self.P < halo:
+                raise ValueError(f"level {l}: {N} rows cannot be split over {self.P} ranks with a {halo}-row halo; "
                                  f"raise cut_level")
             own_lo = self.g * (N // self.P)
             own_hi = (self.g + 1) * (N // self.P) + (1 if self.g == self.P - 1 else 0)
-            row0 = max(own_lo - self.halo, 0)
-            row1 = min(own_hi + self.halo, N + 1)
-            L = SlabLevel(l, N, own_lo, own_hi, self.halo, row0, row1 - row0)
+            row0 = max(own_lo - halo, 0)
+            row1 = min(own_hi + halo, N + 1)
+            L = SlabLevel(l, N, own_lo, own_hi, halo, row0, row1 - row0)
             L.u, L.b, L.tmp = ops.zeros(L.rows, l), ops.zeros(L.rows, l), ops.zeros(L.rows, l)
             self.lv[l] = L
         # cut level: this rank's share of the restricted residual, the gathered
@@ -346,7 +364,8 @@ class DistMultigrid:
         self._sumsq = None
         NC = L.N // 2
         glo, ghi = self._own_coarse_rows(NC)
-        plo, phi = self._range(L, self.ext_post)          # fine rows that receive the correction
+        ext_post, ext_keep, ext_coarse, keep_post = self.ext_post[l], self.ext_keep[l], self.ext_coarse[l], self.keep_post[l]
+        plo, phi = self._range(L, ext_post)               # fine rows that receive the correction
         to_cut = not (l - 1 > self.Lcut)
         Cl = None if to_cut else self.lv[l - 1]
         crow0 = self.c_row0 if to_cut else Cl.row0
@@ -355,21 +374,21 @@ class DistMultigrid:
         fold_post = self.fold and self.mu2 > 0
         # ---- pre-smoothing (PS:581) + residual, restriction, zero coarse guess (PS:604-613) ----
         if fold_pre:
-            need = self.per * self.mu1 + self.ext_keep
+            need = self.per * self.mu1 + ext_keep
             if L.u_halo < need:
                 self.exchange(L, L.u, L.halo)
                 L.u_halo = L.halo
             if Cl is not None:
                 Cl.u.zero_()                                                            # PS:613
-            lo, hi = self._range(L, self.ext_keep)
+            lo, hi = self._range(L, ext_keep)
             L.u, L.tmp, _ = self._timed(L, self.mu1, lo, hi, lambda: self.ops.cycle(
                 self.smoother, l, L.row0, L.u, L.b, L.tmp, lo, hi, self.mu1, self.omega, crow0=crow0, coarse_b=cb,
                 clo=glo - crow0, chi=ghi - crow0, mode=self.restrict_mode))
-            L.u_halo = self.ext_keep
+            L.u_halo = ext_keep
         else:
             if self.mu1 > 0:
-                self._smooth(L, self.mu1, self.ext_keep)                                # PS:581
-            elif L.u_halo < self.ext_keep:
+                self._smooth(L, self.mu1, ext_keep)                                     # PS:581
+            elif L.u_halo < ext_keep:
                 self.exchange(L, L.u, L.halo)
                 L.u_halo = L.halo
             if Cl is not None:
@@ -382,9 +401,9 @@ class DistMultigrid:
             Cl.u_halo = Cl.halo                        # zeros are exact halo values
             self.vcycle(l - 1)
             self._sumsq = None
-            if Cl.u_halo < self.ext_coarse:
-                self.exchange(Cl, Cl.u, self.ext_coarse)
-                Cl.u_halo = self.ext_coarse
+            if Cl.u_halo < ext_coarse:               # never with deep halos: the level below left them valid
+                self.exchange(Cl, Cl.u, ext_coarse)
+                Cl.u_halo = ext_coarse
             ce, ce_row0 = Cl.u, Cl.row0
         else:
             if self.P > 1:
@@ -400,20 +419,20 @@ class DistMultigrid:
             self.coarse.vcycle_from_zero(self.c_b, self.c_e)                            # levels cut..coarsest
             ce, ce_row0 = self.c_e, 0
         # ---- correction (PS:620-624) + post-smoothing (PS:625) (+ the residual norm) -----------
-        L.u_halo = min(L.u_halo, self.ext_post)
+        L.u_halo = min(L.u_halo, ext_post)
         if fold_post:
-            lo, hi = self._range(L, 0)
+            lo, hi = self._range(L, keep_post)
             want = (l == self.Lf)
             L.u, L.tmp, sq = self._timed(L, self.mu2, lo, hi, lambda: self.ops.cycle(
                 self.smoother, l, L.row0, L.u, L.b, L.tmp, lo, hi, self.mu2, self.omega, crow0=ce_row0, coarse_e=ce,
                 want_sumsq=want))
-            L.u_halo = 0
+            L.u_halo = keep_post
             self._sumsq = sq if want else None
         else:
             self.ops.prolong(l, L.row0, L.u, ce_row0, ce, plo, phi, add=True)           # PS:620-624
-            self._smooth(L, self.mu2, 0)                                                # PS:625
+            self._smooth(L, self.mu2, keep_post)                                        # PS:625
             if self.mu2 <= 0:
-                L.u_halo = 0
+                L.u_halo = min(L.u_halo, keep_post)
 
     def residual_norm(self):
         """||b - A u||_2 on the finest level (all ranks get the value)"""

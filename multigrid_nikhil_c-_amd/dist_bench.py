@@ -150,7 +150,7 @@ def run(args, emit=None):
             "config": {
                 "workload": f"2D Poisson {1 << L}^2 (n={n} interior), {L - min(args.coarsest, cut) + 1}-level V({args.mu1},{args.mu2}) cycle, "
                             f"{'weighted Jacobi w=%.4f' % args.omega if args.smoother == 'jacobi' else 'red-black Gauss-Seidel'}, "
-                            f"{args.dtype}, row slabs over {world} GPUs on levels {cut + 1}..{L} ({mg.halo}-row deep halos, "
+                            f"{args.dtype}, row slabs over {world} GPUs on levels {cut + 1}..{L} ({mg.halo}-row deep halos on the finest level, "
                             f"{'RCCL send/recv' if backend == 'nccl' else backend + ' with host-staged halos (rehearsal)'}, "
                             f"{'transfers folded into the smoother passes' if mg.fold else 'separate transfer kernels'}), "
                             f"levels <= {cut} replicated, exact bottom solve at {(1 << min(args.coarsest, cut)) - 1}^2",

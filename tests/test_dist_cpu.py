@@ -31,7 +31,8 @@ def _worker(rank, world, port, cfg, ret):
         ops = CpuSlabOps(torch.float64)
         coarse = OracleCoarseSolver(po, cfg["cut"], cfg["coarsest"], cfg)
         mg = DistMultigrid(ops, coarse, cfg["finest"], cfg["cut"], mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"],
-                           smoother=cfg["smoother"], restrict_mode=cfg["restrict_mode"], fold=cfg.get("fold", True))
+                           smoother=cfg["smoother"], restrict_mode=cfg["restrict_mode"], fold=cfg.get("fold", True),
+                           deep=cfg.get("deep", True))
         L = cfg["finest"]
         n = (1 << L) - 1
         b = po.rhs_sine(L)
@@ -87,20 +88,27 @@ def test_slab_vcycle_matches_single_process_oracle(po, world, smoother, mu1, mu2
     for r in range(world):
         lo, hi, own = got[f"rows{r}"]
         assert np.max(np.abs(own - u_ref[lo - 1:hi - 1])) <= 1e-12 * np.max(np.abs(u_ref))
-    # communication-avoiding plan: one u exchange per cycle on the finest level plus a
-    # right-hand-side and a correction exchange per further distributed level
+    # communication-avoiding plan: one u exchange per cycle on the finest level plus ONE exchange
+    # (the restricted right-hand side) per further distributed level; the correction needs none
     cycles = len(h) - 1
     levels = cfg["finest"] - cfg["cut"]
-    assert got["exch0"] <= cycles * (1 + 2 * (levels - 1)) + 2, got["exch0"]
+    assert got["exch0"] <= cycles * (1 + (levels - 1)) + 2, got["exch0"]
 
 
-def test_two_distributed_levels_and_replicated_coarse(po):
-    cfg = dict(BASE, finest=9, cut=6, coarsest=5, mu1=2, mu2=2, max_cycles=4)
+@pytest.mark.parametrize("deep", [True, False])
+def test_three_distributed_levels_and_replicated_coarse(po, deep):
+    """deep: every level below the finest leaves its correction valid as far into the halos as
+    the level above reads it (3 exchanges per cycle for three slab levels); not deep: the
+    correction is exchanged (5 per cycle)"""
+    cfg = dict(BASE, finest=9, cut=6, coarsest=5, mu1=2, mu2=2, max_cycles=4, deep=deep)
     got = _run(2, cfg)
     u_ref, h_ref = _reference(po, cfg)
     h = np.array(got["hist"])
     assert np.all(np.abs(h - h_ref) <= 1e-10 * h_ref + 1e-13 * h_ref[0])
-    assert got["exch0"] <= (len(h) - 1) * (1 + 2 * 2) + 2, got["exch0"]
+    per_cycle = (1 + 2) if deep else (1 + 2 * 2)
+    assert got["exch0"] <= (len(h) - 1) * per_cycle + 2, got["exch0"]
+    if not deep:
+        assert got["exch0"] > (len(h) - 1) * (1 + 2) + 2
 
 
 def test_eight_ranks_three_distributed_levels(po):
@@ -118,4 +126,4 @@ def test_eight_ranks_three_distributed_levels(po):
         rows += hi - lo
         assert np.max(np.abs(own - u_ref[lo - 1:hi - 1])) <= 1e-12 * np.max(np.abs(u_ref))
     assert rows == (1 << 10) - 1                       # the slabs tile the unknown rows exactly
-    assert got["exch0"] <= (len(h) - 1) * (1 + 2 * 2) + 2, got["exch0"]
+    assert got["exch0"] <= (len(h) - 1) * (1 + 2) + 2, got["exch0"]

@@ -22,7 +22,7 @@ def _setup(pkg, po, cfg, staged=False, fold=None):
     ccfg = dict(mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"], smoother=cfg["smoother"], restrict_mode=0, bottom=0)
     mg = DistMultigrid(HipSlabOps(dt), HipCoarseSolver(cfg["cut"], cfg["coarsest"], ccfg, dt), cfg["finest"], cfg["cut"],
                        mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"], smoother=cfg["smoother"], staged_halo=staged,
-                       fold=cfg.get("fold", fold))
+                       fold=cfg.get("fold", fold), deep=cfg.get("deep"))
     L = cfg["finest"]
     n = (1 << L) - 1
     npdt = np.float32 if dt == torch.float32 else np.float64
@@ -107,7 +107,7 @@ def test_ranks_sharing_one_gpu_equal_single_gpu_solve(pkg, po, world, smoother, 
     world = abs(world)
     big = mu1 >= 7 or world > 2
     cfg = dict(finest=10 if big else 9, cut=7, coarsest=5, mu1=mu1, mu2=mu2, omega=2.0 / 3.0, smoother=smoother,
-               cycles=3, fold=fold, dtype=dtype)
+               cycles=3, fold=fold, dtype=dtype, deep=not (mu1 == 3 and mu2 == 2))   # (3,2): the correction is exchanged
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, 29700 + os.getpid() % 1000, cfg, ret), nprocs=world, join=True)
     n = (1 << cfg["finest"]) - 1
