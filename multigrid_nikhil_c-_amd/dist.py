@@ -237,6 +237,15 @@ class DistMultigrid:
             import os
             deep = os.environ.get("MGX_DIST_DEEP", "1") != "0"
         self.deep = bool(deep)
+        self._plan_halos(finest_level, cut_level, per_sweep, mu1, mu2)
+        if self.deep and any((1 << l) // self.P < self.halo_of[l] for l in self.halo_of):
+            self.deep = False                         # slabs too thin for the deep halos: exchange the correction
+            self._plan_halos(finest_level, cut_level, per_sweep, mu1, mu2)
+        self.halo = self.halo_of[finest_level]
+        self.lv = {}
+        self._alloc_levels(ops, finest_level, cut_level)
+
+    def _plan_halos(self, finest_level, cut_level, per_sweep, mu1, mu2):
         self.keep_post, self.ext_post, self.ext_keep, self.ext_coarse, self.halo_of = {}, {}, {}, {}, {}
         kp = 0
         for l in range(finest_level, cut_level, -1):
@@ -251,8 +260,8 @@ class DistMultigrid:
             self.ext_post[l], self.ext_keep[l], self.ext_coarse[l] = ep, ek, ec
             self.halo_of[l] = max(per_sweep * mu1 + ek, ec, kp)
             kp = ec if self.deep else 0
-        self.halo = self.halo_of[finest_level]
-        self.lv = {}
+
+    def _alloc_levels(self, ops, finest_level, cut_level):
         for l in range(cut_level + 1, finest_level + 1):
             N = 1 << l
             halo = self.halo_of[l]
