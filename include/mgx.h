@@ -149,6 +149,11 @@ MGX_API int mgx_residual_norm(mgx_handle h, int level, double* out);
 MGX_API int mgx_vcycle(mgx_handle h, int level);
 /* fullmultigrid(q, a_h, f_h)  PS:629-650 / MF:175-191 on the finest level. */
 MGX_API int mgx_fmg(mgx_handle h);
+/* One V-cycle from the finest level for A e = b starting from e = 0 (PS:613, 617: the
+ * coarse-grid correction of a caller that owns the finer levels, e.g. the multi-GPU driver).
+ * The zero guess is synthesised by the first smoothing pass where possible (nobody writes or
+ * reads it), and with profiling off the cycle is replayed from a hipGraph. */
+MGX_API int mgx_vcycle_zero(mgx_handle h);
 
 typedef struct {
     int cycles;                 /* cycles run (an FMG pass counts as cycle 1) */

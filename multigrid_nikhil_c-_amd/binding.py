@@ -33,7 +33,7 @@ EXPORTS = [
     "mgx_level_n", "mgx_set_rhs", "mgx_set_rhs_dirichlet", "mgx_set_guess", "mgx_get_solution", "mgx_set_level",
     "mgx_get_level", "mgx_set_level_device", "mgx_get_level_device", "mgx_zero_level", "mgx_fill_rhs", "mgx_fill_guess_random", "mgx_smooth", "mgx_residual",
     "mgx_restrict", "mgx_restrict_rhs", "mgx_prolong_add", "mgx_prolong", "mgx_bottom_solve",
-    "mgx_residual_norm", "mgx_vcycle", "mgx_fmg", "mgx_solve", "mgx_profile_reset",
+    "mgx_residual_norm", "mgx_vcycle", "mgx_vcycle_zero", "mgx_fmg", "mgx_solve", "mgx_profile_reset",
     "mgx_profile_get", "mgx_time_smoother", "mgx_synchronize", "mgx_graphs_cached", "mgx_slab_cycle", "mgx_level_pitch",
     "mgx_slab_jacobi", "mgx_slab_rbgs", "mgx_slab_restrict", "mgx_slab_prolong",
     "mgx_slab_residual_sumsq", "mgx_slab_scratch_doubles",
@@ -109,7 +109,7 @@ def lib() -> C.CDLL:
     L.mgx_smooth.argtypes = [vp, C.c_int, C.c_int]
     for name in ("mgx_residual", "mgx_restrict", "mgx_restrict_rhs", "mgx_prolong_add", "mgx_prolong", "mgx_vcycle"):
         getattr(L, name).argtypes = [vp, C.c_int]
-    for name in ("mgx_bottom_solve", "mgx_fmg", "mgx_profile_reset", "mgx_synchronize", "mgx_graphs_cached"):
+    for name in ("mgx_bottom_solve", "mgx_fmg", "mgx_vcycle_zero", "mgx_profile_reset", "mgx_synchronize", "mgx_graphs_cached"):
         getattr(L, name).argtypes = [vp]
     L.mgx_residual_norm.argtypes = [vp, C.c_int, dp]
     L.mgx_solve.argtypes = [vp, C.c_double, C.c_int, C.POINTER(Stats), dp, C.c_int]
@@ -303,6 +303,10 @@ class Multigrid:
 
     def vcycle(self, level=None):
         self._chk(lib().mgx_vcycle(self._h, self.cfg.finest_level if level is None else level), "mgx_vcycle")
+
+    def vcycle_zero(self):
+        """one V-cycle from the finest level for A e = b, starting from e = 0"""
+        self._chk(lib().mgx_vcycle_zero(self._h), "mgx_vcycle_zero")
 
     def smooth(self, level, mu):
         self._chk(lib().mgx_smooth(self._h, level, mu), "mgx_smooth")

@@ -609,39 +609,55 @@ void set_buffer_state(mgx_solver* s, const std::vector<void*>& v)
     for (int l = s->cfg.coarsest_level; l <= s->cfg.finest_level; ++l) { s->lv[l].u = v[i++]; s->lv[l].tmp = v[i++]; }
 }
 
-int cycle_and_norm_direct(mgx_solver* s, double* r)
+// want_norm: the body ends with the residual norm (mgx_solve's loop);  zero_start: the cycle
+// starts from u = 0 (PS:613; the correction cycle of a coarse-grid solver), synthesised by the
+// first pass where it can be, so nobody writes or reads the zeros
+int cycle_body_direct(mgx_solver* s, bool want_norm, bool zero_start, double* r)
 {
     const int L = s->cfg.finest_level;
     Level& l = s->lv[L];
     s->norm_blocks_ready = 0;
-    s->want_norm = true; s->zero_in_level = -1;
+    s->want_norm = want_norm; s->zero_in_level = -1;
+    if (zero_start && L > s->cfg.coarsest_level) {
+        if (zero_in_ok(s, L)) s->zero_in_level = L;
+        else { int rc = zero_u(s, L); if (rc) return rc; }
+    }
     vcycle(s, L);
     s->want_norm = false;
+    if (!want_norm) return MGX_OK;
     return residual_norm_grid(s, l, l.u, l.b, r, MGX_PROF_NORM_FINE);
 }
 
-int cycle_and_norm(mgx_solver* s, double* r)
+int cycle_body(mgx_solver* s, bool want_norm, bool zero_start, double* r)
 {
-    if (!s->use_graph || s->cfg.profile || s->mixed) return cycle_and_norm_direct(s, r);
+    if (!s->use_graph || s->cfg.profile || s->mixed) return cycle_body_direct(s, want_norm, zero_start, r);
     const int L = s->cfg.finest_level;
-    const std::vector<void*> before = buffer_state(s);
+    std::vector<void*> before = buffer_state(s);
+    // the two flavours are different graphs: tag the key
+    before.push_back(reinterpret_cast<void*>((uintptr_t)((want_norm ? 1 : 0) | (zero_start ? 2 : 0))));
     mgx_solver::CycleGraph* g = nullptr;
     for (auto& c : s->graphs)
         if (c.before == before) { g = &c; break; }
     if (!g) {
-        if (s->graphs.size() >= 8) return cycle_and_norm_direct(s, r);
+        if (s->graphs.size() >= 8) return cycle_body_direct(s, want_norm, zero_start, r);
         const double fu0 = s->fine_updates;
+        const std::vector<void*> state0 = buffer_state(s);
         if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
             s->use_graph = 0;
-            return cycle_and_norm_direct(s, r);
+            return cycle_body_direct(s, want_norm, zero_start, r);
         }
         // enqueue the body (nothing executes while capturing; the host-side bookkeeping does)
+        int rc = MGX_OK;
         s->norm_blocks_ready = 0;
-        s->want_norm = true; s->zero_in_level = -1;
+        s->want_norm = want_norm; s->zero_in_level = -1;
+        if (zero_start && L > s->cfg.coarsest_level) {
+            if (zero_in_ok(s, L)) s->zero_in_level = L;
+            else rc = zero_u(s, L);
+        }
         vcycle(s, L);
         s->want_norm = false;
-        const int rc = enqueue_norm(s, s->lv[L], s->lv[L].u, s->lv[L].b, MGX_PROF_NORM_FINE);
+        if (rc == MGX_OK && want_norm) rc = enqueue_norm(s, s->lv[L], s->lv[L].u, s->lv[L].b, MGX_PROF_NORM_FINE);
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamEndCapture(s->stream, &graph);
@@ -650,10 +666,10 @@ int cycle_and_norm(mgx_solver* s, double* r)
         if (rc != MGX_OK || e != hipSuccess) {
             // undo the bookkeeping of the cycle that was not run, and stay on the direct path
             (void)hipGetLastError();
-            set_buffer_state(s, before);
+            set_buffer_state(s, state0);
             s->fine_updates = fu0;
             s->use_graph = 0;
-            return cycle_and_norm_direct(s, r);
+            return cycle_body_direct(s, want_norm, zero_start, r);
         }
         mgx_solver::CycleGraph c;
         c.before = before; c.after = buffer_state(s); c.exec = exec; c.fine_updates = s->fine_updates - fu0;
@@ -666,10 +682,13 @@ int cycle_and_norm(mgx_solver* s, double* r)
     s->norm_blocks_ready = 0;
     s->zero_in_level = -1;
     HIPCHK(s, hipGraphLaunch(g->exec, s->stream));
+    if (!want_norm) return MGX_OK;
     HIPCHK(s, hipStreamSynchronize(s->stream));
     *r = std::sqrt(*s->sum_host);
     return MGX_OK;
 }
+
+inline int cycle_and_norm(mgx_solver* s, double* r) { return cycle_body(s, true, false, r); }
 
 double pow2_floor(double x)
 {
@@ -1062,6 +1081,15 @@ int mgx_vcycle(mgx_handle s, int level)
     OP_PROLOGUE(s->cfg.coarsest_level)
     s->zero_in_level = -1;
     vcycle(s, level);
+    OP_EPILOGUE
+}
+
+int mgx_vcycle_zero(mgx_handle s)
+{
+    if (!s) return MGX_ERR_INVALID;
+    double unused = 0.0;
+    int rc = cycle_body(s, false, true, &unused);
+    if (rc) return rc;
     OP_EPILOGUE
 }
 

@@ -170,8 +170,7 @@ class HipCoarseSolver:
         """e_full <- one V-cycle (PS:575-627) for A e = b_full from e = 0 (PS:613)"""
         torch.cuda.current_stream().synchronize()          # the handle runs on its own stream
         self.mg.set_level_device(self.level, B.VEC_B, b_full.data_ptr())
-        self.mg.zero_level(self.level, B.VEC_U)
-        self.mg.vcycle(self.level)
+        self.mg.vcycle_zero()            # from e = 0, replayed from a hipGraph
         self.mg.get_level_device(self.level, B.VEC_U, e_full.data_ptr())
 
 

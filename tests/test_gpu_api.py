@@ -133,3 +133,28 @@ def test_nonzero_dirichlet_data_known_answer(pkg, po):
         with pytest.raises(pkg.MgxError, match="ring"):
             pkg.lib()  # keep lib loaded
             mg._chk(pkg.lib().mgx_set_rhs_dirichlet(mg._h, b.ctypes.data, b.size, b.ctypes.data, 7), "mgx_set_rhs_dirichlet")
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+@pytest.mark.parametrize("cfg", [dict(finest_level=9, coarsest_level=6, mu1=3, mu2=2), dict(finest_level=11, coarsest_level=7, mu1=10, mu2=10),
+                                 dict(finest_level=8, coarsest_level=5, mu1=2, mu2=1, smoother=1), dict(finest_level=7, coarsest_level=7),
+                                 dict(finest_level=9, coarsest_level=6, mu1=0, mu2=2)])
+def test_vcycle_zero_equals_zero_guess_then_vcycle(pkg, po, monkeypatch, cfg, graph):
+    """mgx_vcycle_zero (implicit zero guess, hipGraph replay) against zero_level + mgx_vcycle, called
+    several times on changing right-hand sides (what the multi-GPU driver's coarse solver does)"""
+    monkeypatch.setenv("MGX_GRAPH", graph)
+    L = cfg["finest_level"]
+    n = (1 << L) - 1
+    rng = np.random.default_rng(5)
+    with pkg.Multigrid(**cfg) as a, pkg.Multigrid(**cfg) as b:
+        for it in range(4):
+            f = rng.uniform(-1, 1, (n, n))
+            a.set_rhs(f)
+            a.set_guess(rng.uniform(-1, 1, (n, n)))      # stale data the call must ignore
+            a.vcycle_zero()
+            b.set_rhs(f)
+            b.zero_level(L, pkg.VEC_U)
+            b.vcycle(L)
+            assert np.array_equal(a.get_solution(), b.get_solution()), (cfg, it)
+        if graph == "1":
+            assert 1 <= a.graphs_cached() <= 2
