@@ -140,8 +140,8 @@ def cpu_baseline(args):
 
 def pmc_traffic(workload_key):
     """HBM bytes per launch of the dominant kernel, from the committed rocprofv3
-    PMC passes (profiles/*.json written by tools/pmc_summary.py); None if there
-    is no measurement for this exact workload."""
+    PMC passes (profiles/pmc_traffic.json, numbers from the tables tools/prof_summary.py
+    prints); None if there is no measurement for this exact workload."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
@@ -182,25 +182,32 @@ def run_single(args):
     assert st.cycles == args.steps
     updates = st.fine_updates
     value = updates / secs
-    # ---- roofline of the dominant kernel: the finest-level smoother ----
-    # One launch of k_jacobi_fused<T,K> performs K sweeps in one pass over HBM, so
-    # the algorithmic bytes it is charged with are K * 3*sizeof(T) * n^2 (SURVEY
-    # §8d's per-update figure x the updates the launch performs) while its HBM
-    # traffic stays ~3*sizeof(T)*n^2: `frac` can exceed 1; `traffic` shows why.
+    # ---- roofline of the dominant kernel: the finest-level smoother passes ----
+    # `achieved` charges a launch with the bytes it MUST move, once: one pass reads v and b and
+    # writes v' (3*sizeof(T)*n^2, SURVEY §8d's 12 / 24 B per point) however many sweeps it performs,
+    # plus the folded transfers' coarse traffic (the restricted right-hand side written by the last
+    # pre-smoothing pass, the coarse correction read by the first post-smoothing pass: sizeof(T)*n_c^2
+    # each, once per V-cycle).  The K sweeps a fused pass performs per byte are reported separately
+    # (`sweeps_per_pass`, `effective_gbs_per_sweep`): that figure is a throughput multiple, not a
+    # roofline fraction.
     es = BYTES[args.dtype]
     sm_ms = prof["ms"][0]               # MGX_PROF_SMOOTH_FINE
     sm_launches = max(prof["launches"][0], 1)
     sm_sweeps = prof["sweeps"][0]
     avg_ms = sm_ms / sm_launches
     sweeps_per_launch = sm_sweeps / sm_launches
-    alg_bytes_per_launch = 3.0 * es * n * n * sweeps_per_launch
+    nc = (1 << (L - 1)) - 1
+    folded = sweeps_per_launch > 1.0 and L > cfg["coarsest_level"]
+    pass_bytes = 3.0 * es * n * n
+    coarse_bytes_per_cycle = (2.0 * es * nc * nc) if folded else 0.0
+    alg_bytes_per_launch = pass_bytes + coarse_bytes_per_cycle * args.steps / sm_launches
     achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
     tname = "double" if es == 8 else "float"
-    if args.smoother == "rbgs":
+    if args.smoother == "rbgs" and sweeps_per_launch <= 1.0:
         kernel = f"k_rbgs<{tname}>"
     elif sweeps_per_launch > 1.0:
         kernel = (f"k_jacobi_fused<{tname},K> / k_jacobi_cycle<{tname},K,PRE,POST> "
-                  f"(finest-level smoother passes, K = {sweeps_per_launch:g} sweeps per launch on average; "
+                  f"(finest-level smoother passes, K = {sweeps_per_launch:g} sweeps per pass on average; "
                   f"the cycle's correction, residual+restriction and norm ride in the same passes)")
     else:
         kernel = f"k_jacobi_rows<{tname}>"
@@ -240,8 +247,13 @@ def run_single(args):
             "frac": achieved / HBM_PEAK_GBS,
             "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
             "traffic": traffic,
+            "traffic_source": ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                               "(committed summaries profiles/r0*_pmc_summary.md, written by tools/prof_summary.py), gfx950 "
+                               "correction (2*FETCH_SIZE + WRITE_SIZE)*1024; NOT measured in this run") if traffic else None,
             "hbm_physical_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+            "sweeps_per_pass": sweeps_per_launch,
+            "effective_gbs_per_sweep": 3.0 * es * n * n * sweeps_per_launch / (avg_ms * 1e-3) / 1e9,
             "avg_launch_ms": avg_ms,
             "launches_timed": sm_launches,
             "sweeps_timed": sm_sweeps,
@@ -306,9 +318,110 @@ def run_single(args):
     emit(out)
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def visible_devices():
+    """HIP devices this process could use, WITHOUT initialising the GPU (the launcher must stay
+    a process that never touched it: its children are the ranks)."""
+    try:
+        import torch
+
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` started as ONE plain process (no torchrun): become the launcher.
+    Start exactly N child ranks of this same script, one per GPU, with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set; relay rank 0's single JSON line; fail if any rank fails.  Nothing
+    here touches the GPU and nothing is exec'ed over a process that did."""
+    import subprocess
+
+    n = args.gpus
+    rehearsal = bool(os.environ.get("MGX_DIST_SINGLE_DEVICE")) or bool(os.environ.get("MGX_BENCH_DRYRUN"))
+    ndev = visible_devices()
+    if ndev < n and not rehearsal:
+        emit({"metric": "fine_grid_stencil_updates_per_sec", "value": None, "unit": "updates/s", "n_gpus": n,
+              "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong",
+              "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+              "config": {"workload": f"2D Poisson {1 << (args.level or 14)}^2, row slabs over {n} GPUs"},
+              "error": f"--gpus {n} needs {n} HIP devices, {ndev} visible (rehearsal on fewer devices: "
+                       f"MGX_DIST_SINGLE_DEVICE=1 MGX_DIST_BACKEND=gloo)"})
+        sys.exit(2)
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MGX_BENCH_LAUNCHED="1")
+        # rank 0's stdout is the result line; every rank's stderr goes to ours
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=2))
+    if os.environ.get("MGX_BENCH_LAUNCH_LOG"):       # tests: which ranks were started
+        with open(os.environ["MGX_BENCH_LAUNCH_LOG"], "w") as fh:
+            json.dump({"ranks": n, "pids": [p.pid for p in procs], "port": port}, fh)
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for ln in (out0 or b"").decode(errors="replace").splitlines():
+        if ln.lstrip().startswith("{"):
+            line = ln
+    if line is not None:
+        os.write(_REAL_STDOUT, (line + "\n").encode())
+    if any(codes) or line is None:
+        sys.stderr.write(f"bench.py launcher: rank exit codes {codes}, result line {'present' if line else 'MISSING'}\n")
+        sys.exit(1)
+
+
+def dry_run(args, world):
+    """MGX_BENCH_DRYRUN=1 (tests/test_bench_launcher.py, CPU): every rank joins a gloo group and is
+    counted by an all_reduce; rank 0 prints the line shape with the rank count the collective saw.
+    No solver, no GPU: this exercises the launcher and the rendezvous only."""
+    import torch
+    import torch.distributed as dist
+
+    seen = 1
+    if os.environ.get("MGX_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):
+        sys.exit(7)                     # test hook: a rank that dies
+    if world > 1:
+        import datetime
+
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=20))
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        rank = dist.get_rank()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        rank = 0
+    if seen != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the collective saw {seen} ranks\n")
+        sys.exit(3)
+    if rank == 0:
+        emit({"metric": "fine_grid_stencil_updates_per_sec", "value": None, "unit": "updates/s", "n_gpus": seen,
+              "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_seen_by_collective": seen})
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, sys.argv[1:])
+        return
+    if args.gpus != world and not (args.gpus <= 1 and world <= 1):
+        # never report a GPU count other than the ranks that really run
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; refusing to run\n")
+        sys.exit(2)
+    if os.environ.get("MGX_BENCH_DRYRUN"):
+        dry_run(args, world)
+        return
     if args.gpus <= 1 and world <= 1:
         if args.level is None:
             args.level = 13

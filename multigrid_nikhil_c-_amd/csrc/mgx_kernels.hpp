@@ -68,12 +68,15 @@ __device__ __forceinline__ float  last(const float4& v)   { return v.w; }
 // value held by the lane one to the left / right: DPP wavefront shifts
 // (v_mov_b32_dpp wave_shr:1 / wave_shl:1), i.e. plain VALU moves with no LDS
 // round trip - __shfl_up/down lower to ds_bpermute_b32, whose latency sits in
-// the serial level-to-level dependency chain of the fused kernels.  Semantics
-// checked on MI355X: identical to __shfl_up/down(x, 1, 64), edge lanes keep
-// their own value (lane 0's "left" and lane 63's "right" are don't-cares:
-// halo lanes never store).
-__device__ __forceinline__ int dpp_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int dpp_shl1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x130, 0xf, 0xf, false); }
+// the serial level-to-level dependency chain of the fused kernels.  Semantics:
+// __shfl_up/down(x, 1, 64) except on the edge lanes, which get 0 (lane 0's "left"
+// and lane 63's "right" are don't-cares: halo lanes never store).
+// bound_ctrl = 1: the lane with no source (lane 0 of wave_shr, lane 63 of wave_shl) gets 0 and
+// the destination needs no previous value - with `old = x` the compiler had to copy x into the
+// destination first (one extra v_mov_b32 per shifted dword: 20 of the 131 vector instructions
+// of a K = 5 row step in double).
+__device__ __forceinline__ int dpp_shr1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int dpp_shl1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true); }
 __device__ __forceinline__ float from_left(float x)  { return __int_as_float(dpp_shr1(__float_as_int(x))); }
 __device__ __forceinline__ float from_right(float x) { return __int_as_float(dpp_shl1(__float_as_int(x))); }
 __device__ __forceinline__ double from_left(double x)
@@ -96,7 +99,9 @@ __device__ __forceinline__ Tile wave_tile(int strips, int chunks)
 {
     const int per_xcd = gridDim.x >> 3;
     const int b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const long g = (long)b * kWavesPerBlock + (threadIdx.x >> 6);
+    // the wave index as a scalar: everything derived from it (chunk, rows, row offsets, the
+    // row predicates) then lives in SGPRs and costs no vector instruction
+    const long g = (long)b * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     Tile t;
     t.chunk = (int)(g / strips);
     t.strip = (int)(g - (long)t.chunk * strips);

@@ -1,7 +1,9 @@
 /*
  * mg_oracle.c — CPU oracle for the 2-D Poisson multigrid hot path.
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (no reference fixtures exist and
- * the reference cannot be built in this image) — see mg_oracle.h.
+ * TEST INFRASTRUCTURE ONLY.  Parity: prolongation, load vector and the stencil
+ * are pinned by reference-computed data (oracle/_ref, tests/golden/ref_ps.npz);
+ * the smoother, residual and the schedules are UNPINNED (the reference's
+ * oneMKL/SYCL path cannot be built in this image) — see mg_oracle.h.
  *
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp -shared)
  */

@@ -5,13 +5,24 @@
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library, and only as the checker / reported CPU baseline.
  *
- * PARITY UNPINNED.  The reference (nikhilTkur/Multigrid_Nikhil_C-) ships no
- * tests, fixtures or golden vectors, and it cannot be built here: it needs
- * <CL/sycl.hpp>, oneMKL and Eigen, none of which exist in this image, and no
- * stand-ins are written for them.  This file is therefore a plain-C
- * restatement of the reference's *intended* algorithm; every place where the
- * restatement departs from the literal text is a row of SURVEY.md §2.3
- * (D1..D12) and is called out next to the function it affects.
+ * PARITY PARTLY PINNED.  The reference (nikhilTkur/Multigrid_Nikhil_C-) ships no
+ * tests, fixtures or golden vectors, and its hot path cannot be built here: it
+ * needs <CL/sycl.hpp>, oneMKL and Eigen, none of which exist in this image, and
+ * no stand-ins are written for them.  What IS buildable - the standard-C++
+ * functions of Poissons_SYCL.cpp - is compiled from the source where it lies
+ * (oracle/build_ref.sh -> oracle/_ref/libps_ref.so) and its outputs are frozen
+ * in tests/golden/ref_ps.npz; against them this oracle is
+ *   bit-exact   orc_prolong_f32        == interpolation2d       PS:337-425   (A4)
+ *   exact       orc_rhs_constant       == -globalforcefunction  PS:283-335   (A10, sign D1)
+ *   exact       the 5-point operator   == -globalstiffenssmatrix PS:200-281, numbering PS:227-233
+ * (tests/test_ref_pins.py).  Still UNPINNED - plain-C restatements of the
+ * reference's *intended* algorithm, checked only against definitions and
+ * identities: Jacobi (PS:125-147), the residual block (PS:591-608), the
+ * correction add, the V-cycle and FMG schedules (oneMKL / SYCL call sites),
+ * restriction (PS:531-546 is identically zero as written, D3) and everything
+ * the reference lacks (RB-GS, exact bottom solve, mixed precision).  Every
+ * place where the restatement departs from the literal text is a row of
+ * SURVEY.md §2.3 (D1..D12) and is called out next to the function it affects.
  *
  * Citations: PS = /root/reference/Poissons_SYCL.cpp,
  *            MF = /root/reference/Multigrid_functions.cpp.
