@@ -53,7 +53,8 @@ enum { MGX_BOTTOM_EXACT = 0, MGX_BOTTOM_SMOOTH = 1 };
  * MF:43-48 holds the draft's values of the same names. */
 typedef struct {
     int finest_level;     /* PS:17  */
-    int coarsest_level;   /* PS:18  */
+    int coarsest_level;   /* PS:18; >= 2, and <= 8 with bottom = EXACT (the dense sine-transform
+                             solve holds (2^L - 1)^2 matrices: 255^2 at level 8; PS:18 uses 7) */
     int mu0;              /* PS:20  FMG runs mu0+1 V-cycles per level (PS:646) */
     int mu1;              /* PS:21  pre-smoothing sweeps  */
     int mu2;              /* PS:22  post-smoothing sweeps */
@@ -124,7 +125,11 @@ MGX_API int mgx_fill_rhs(mgx_handle h, int kind, double f);
 /* u ~ U(-1,1) from a counter-based generator keyed on (seed, index). */
 MGX_API int mgx_fill_guess_random(mgx_handle h, uint64_t seed);
 
-/* ---- grid operators (one call = the reference function named) ------------ */
+/* ---- grid operators (one call = the reference function named) ------------
+ * On a dtype MIXED handle the finest level holds double data for the accessors above and a
+ * float correction / residual pair for the inner cycle, so the operators and schedules below
+ * return MGX_ERR_STATE when asked to act on the finest level (use mgx_solve there, or a F64 /
+ * F32 handle); the coarser levels of a MIXED handle are ordinary float levels. */
 /* jacobirelaxation(q, a_lu, size, v, f, mu)  PS:125-147 / MF:75-96; with
  * smoother = RBGS: mu red-black Gauss-Seidel sweeps.  Acts on U,B of `level`. */
 MGX_API int mgx_smooth(mgx_handle h, int level, int mu);

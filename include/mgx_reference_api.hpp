@@ -11,7 +11,8 @@
 //   ------------------------------------------------------------------  ---------------------------
 //   cl::sycl::queue q;                                     PS:659       mgxref::queue q;
 //   jacobi_matrices[level - coarsest_level] = {...}        PS:33,661-690 mgxref::build_hierarchy(...)
-//   jacobirelaxation(q, a_lu, a_size, v, fh, mu)           PS:125       same name / argument order
+//   jacobirelaxation(q, a_lu, a_size, v, fh, mu)           PS:125       same name, same six arguments
+//                                                                       (+ a 5-argument overload taking the level entry)
 //   restriction2d(vec_h)                                   PS:531       same
 //   interpolation2d(vec_2h)                                PS:337       same
 //   vcyclemultigrid(q, a_h, vec_h, f_h)                    PS:575       same
@@ -40,12 +41,22 @@ namespace mgxref {
 
 struct queue {};   // stands where cl::sycl::queue stands in the reference's signatures (PS:659)
 
-// PS:24-30 matrix_elements_for_jacobi: what a level "matrix" is in a matrix-free
-// solver: a handle on the hierarchy plus the level's size.
-struct matrix_elements_for_jacobi {
+// oneapi::mkl::sparse::matrix_handle_t in the reference's signatures (PS:26, 28, 125): what a
+// sparse-matrix handle is in a matrix-free solver - the hierarchy it belongs to and its level.
+struct matrix_handle_t {
     mgx_handle handle = nullptr;
     int level = 0;
-    std::int32_t size = 0;   // number of unknowns (PS:689)
+};
+
+// PS:24-30 matrix_elements_for_jacobi, same three members in the same order (the diagonal and
+// the off-diagonal part of one level's operator are the same matrix-free stencil here), plus the
+// two fields the wrappers below read directly.
+struct matrix_elements_for_jacobi {
+    matrix_handle_t a_d_handle;      // PS:26
+    matrix_handle_t a_lu_handle;     // PS:28
+    std::int32_t size = 0;           // PS:29: number of unknowns (PS:689)
+    mgx_handle handle = nullptr;
+    int level = 0;
 };
 
 // the reference's compile-time globals (PS:17-22), run-time here
@@ -104,7 +115,8 @@ inline std::vector<matrix_elements_for_jacobi>& build_hierarchy(const parameters
     H.jacobi_matrices.assign(prm.finest_level - prm.coarsest_level + 1, {});
     for (int level = prm.coarsest_level; level <= prm.finest_level; ++level) {   // PS:661
         const std::int32_t n = mgx_level_n(level);
-        H.jacobi_matrices[level - prm.coarsest_level] = {H.handle, level, n * n};   // PS:665, 689
+        const matrix_handle_t mh{H.handle, level};
+        H.jacobi_matrices[level - prm.coarsest_level] = {mh, mh, n * n, H.handle, level};   // PS:665, 680-689
     }
     return H.jacobi_matrices;
 }
@@ -124,16 +136,30 @@ template <typename Real> inline std::vector<Real> get(mgx_handle h, int level, i
     return v;
 }
 
-// PS:125-147.  a_lu / a_size become the level entry; mutates v AND returns it.
+// PS:125-147, the reference's own six arguments (called as PS:581 does:
+// jacobirelaxation(q, a_h.a_lu_handle, a_h.size, vec_h, f_h, mu1)); mutates v AND returns it (PS:146).
+// a_size is checked against the handle's level, as the only use the reference makes of it
+// (PS:129-131 sizes its scratch vectors with it).
 template <typename Real>
-inline std::vector<Real> jacobirelaxation(queue&, matrix_elements_for_jacobi& a, std::vector<Real>& v,
+inline std::vector<Real> jacobirelaxation(queue&, matrix_handle_t a_lu, std::int32_t a_size, std::vector<Real>& v,
                                           std::vector<Real>& fh, const int& mu)
 {
-    put(a.handle, a.level, MGX_VEC_U, v);
-    put(a.handle, a.level, MGX_VEC_B, fh);
-    check(mgx_smooth(a.handle, a.level, mu), a.handle, "mgx_smooth");
-    v = get<Real>(a.handle, a.level, MGX_VEC_U);
+    const std::int32_t n = mgx_level_n(a_lu.level);
+    if (a_size != n * n || v.size() != std::size_t(a_size) || fh.size() != std::size_t(a_size))
+        throw std::runtime_error("jacobirelaxation: a_size / vector lengths do not match the level of a_lu");
+    put(a_lu.handle, a_lu.level, MGX_VEC_U, v);
+    put(a_lu.handle, a_lu.level, MGX_VEC_B, fh);
+    check(mgx_smooth(a_lu.handle, a_lu.level, mu), a_lu.handle, "mgx_smooth");
+    v = get<Real>(a_lu.handle, a_lu.level, MGX_VEC_U);
     return v;
+}
+
+// convenience overload on the level entry
+template <typename Real>
+inline std::vector<Real> jacobirelaxation(queue& q, matrix_elements_for_jacobi& a, std::vector<Real>& v,
+                                          std::vector<Real>& fh, const int& mu)
+{
+    return jacobirelaxation<Real>(q, a.a_lu_handle, a.size, v, fh, mu);
 }
 
 // PS:531-546

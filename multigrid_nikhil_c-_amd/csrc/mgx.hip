@@ -383,7 +383,7 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
         else if (P) blocks = launch_cycle<T, 1, 0, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
         else if (Q == 1) blocks = launch_cycle<T, 0, 1, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
         else if (Q == 2) blocks = launch_cycle<T, 0, 2, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
-        else if (!rbgs && K == 1) launch_jacobi<T>(src, b, dst, l.N, l.pitch, 1, l.N, s->cfg.omega, s->rows_per_chunk, s->stream);
+        else if (!rbgs && K == 1) (void)launch_jacobi<T>(src, b, dst, l.N, l.pitch, 1, l.N, s->cfg.omega, s->rows_per_chunk, s->stream, l.rows);
         else (void)launch_fused<T, SM>(K, src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, 0, R, s->stream, l.rows, fa.zero_in);
         if (Q == 2) *norm_blocks = blocks;
         std::swap(src, dst);
@@ -571,10 +571,10 @@ int enqueue_norm(mgx_solver* s, const Level& l, const void* u, const void* b, in
         Prof p(s, cls, 2);
         if (l.f64)
             launch_residual<double, 1>((const double*)u, (const double*)b, nullptr, 0, s->partial, s->sum_dev, 1.0,
-                                       l.N, l.pitch, 1, l.N, s->rows_per_chunk, s->stream, s->partial_cap);
+                                       l.N, l.pitch, 1, l.N, s->rows_per_chunk, s->stream, s->partial_cap, l.rows);
         else
             launch_residual<float, 1>((const float*)u, (const float*)b, nullptr, 0, s->partial, s->sum_dev, 1.0,
-                                      l.N, l.pitch, 1, l.N, s->rows_per_chunk, s->stream, s->partial_cap);
+                                      l.N, l.pitch, 1, l.N, s->rows_per_chunk, s->stream, s->partial_cap, l.rows);
     }
     s->norm_blocks_ready = 0;
     HIPCHK(s, hipMemcpyAsync(s->sum_host, s->sum_dev, sizeof(double), hipMemcpyDeviceToHost, s->stream));
@@ -997,10 +997,21 @@ int mgx_fill_guess_random(mgx_handle s, uint64_t seed)
 }
 
 // ---- operators ------------------------------------------------------------------------
+// On a MIXED handle the finest level exists twice: the double u, b the accessors address
+// (mgx_set_level / mgx_get_level / mgx_set_rhs ...) and the float correction / residual scratch of
+// the inner cycle, which is what the working hierarchy holds at that level.  An operator or
+// schedule call there would silently act on the scratch pair: refuse it (only mgx_solve, and
+// operators on the coarser float levels, are meaningful on a MIXED handle).
+#define MIXED_GUARD(lvl)                                                                  \
+    if (s->mixed && (lvl) == s->cfg.finest_level)                                         \
+        return s->fail(MGX_ERR_STATE, "dtype MIXED: operators and schedules are not defined on the finest level " \
+                                      "(double data, float inner cycle); use mgx_solve, or a F64 / F32 handle");
+
 #define OP_PROLOGUE(lvl_min)                                                              \
     if (!s) return MGX_ERR_INVALID;                                                       \
     if (level < (lvl_min) || level > s->cfg.finest_level)                                 \
-        return s->fail(MGX_ERR_INVALID, "level out of range for this operator");
+        return s->fail(MGX_ERR_INVALID, "level out of range for this operator");          \
+    MIXED_GUARD(level)
 
 #define OP_EPILOGUE                                                                       \
     HIPCHK(s, hipGetLastError());                                                         \
@@ -1023,10 +1034,10 @@ int mgx_residual(mgx_handle s, int level)
     if (rc) return rc;
     if (l.f64)
         launch_residual<double, 0>((const double*)l.u, (const double*)l.b, l.r, l.pitch, nullptr, nullptr, 1.0, l.N,
-                                   l.pitch, 1, l.N, s->rows_per_chunk, s->stream);
+                                   l.pitch, 1, l.N, s->rows_per_chunk, s->stream, -1, l.rows);
     else
         launch_residual<float, 0>((const float*)l.u, (const float*)l.b, l.r, l.pitch, nullptr, nullptr, 1.0, l.N,
-                                  l.pitch, 1, l.N, s->rows_per_chunk, s->stream);
+                                  l.pitch, 1, l.N, s->rows_per_chunk, s->stream, -1, l.rows);
     OP_EPILOGUE
 }
 
@@ -1062,6 +1073,7 @@ int mgx_bottom_solve(mgx_handle s)
 {
     if (!s) return MGX_ERR_INVALID;
     if (s->cfg.bottom != MGX_BOTTOM_EXACT) return s->fail(MGX_ERR_STATE, "handle was created with bottom = SMOOTH");
+    MIXED_GUARD(s->cfg.coarsest_level)
     bottom_solve(s);
     OP_EPILOGUE
 }
@@ -1087,6 +1099,7 @@ int mgx_vcycle(mgx_handle s, int level)
 int mgx_vcycle_zero(mgx_handle s)
 {
     if (!s) return MGX_ERR_INVALID;
+    MIXED_GUARD(s->cfg.finest_level)
     double unused = 0.0;
     int rc = cycle_body(s, false, true, &unused);
     if (rc) return rc;
@@ -1096,6 +1109,7 @@ int mgx_vcycle_zero(mgx_handle s)
 int mgx_fmg(mgx_handle s)
 {
     if (!s) return MGX_ERR_INVALID;
+    MIXED_GUARD(s->cfg.finest_level)
     int rc = fmg(s);
     if (rc) return rc;
     OP_EPILOGUE
@@ -1161,7 +1175,7 @@ int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double
                     // no scaled residual is pending yet: produce it now
                     Prof p(s, MGX_PROF_NORM_FINE, 2);
                     launch_residual<double, 2>((const double*)d.u, (const double*)d.b, w.b, w.pitch, s->partial,
-                                               s->sum_dev, 1.0 / scale, d.N, d.pitch, 1, d.N, rpc, s->stream, s->partial_cap);
+                                               s->sum_dev, 1.0 / scale, d.N, d.pitch, 1, d.N, rpc, s->stream, s->partial_cap, d.rows);
                 }
                 // PS:613-style zero guess: implicit when the first pass can synthesise it
                 if (zero_in_ok(s, L)) s->zero_in_level = L;
@@ -1194,7 +1208,7 @@ int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double
                     std::swap(d.u, d.tmp);
                 } else {
                     launch_residual<double, 2>((const double*)d.u, (const double*)d.b, w.b, w.pitch, s->partial,
-                                               s->sum_dev, 1.0 / next_scale, d.N, d.pitch, 1, d.N, rpc, s->stream, s->partial_cap);
+                                               s->sum_dev, 1.0 / next_scale, d.N, d.pitch, 1, d.N, rpc, s->stream, s->partial_cap, d.rows);
                 }
             }
             HIPCHK(s, hipMemcpyAsync(s->sum_host, s->sum_dev, sizeof(double), hipMemcpyDeviceToHost, s->stream));
@@ -1268,6 +1282,8 @@ static int slab_check(const mgx_slab* s)
 {
     if (!s || s->level < 2 || s->level > 15 || s->rows < 1) return MGX_ERR_INVALID;
     if (s->dtype != MGX_DTYPE_F32 && s->dtype != MGX_DTYPE_F64) return MGX_ERR_INVALID;
+    // the slab must lie inside the grid: rows row0 .. row0 + rows - 1 of rows 0 .. N
+    if (s->row0 < 0 || s->row0 + s->rows > (1 << s->level) + 1) return MGX_ERR_INVALID;
     return MGX_OK;
 }
 
@@ -1384,7 +1400,7 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
                 if (rc < 0) return MGX_ERR_INVALID;
                 if (Q == 2) blocks = rc;
             } else if (!rbgs && K == 1) {
-                launch_jacobi<T>(src, b, dst, N, pitch, lo, hi, omega, env_int("MGX_ROWS", 0), st);
+                if (launch_jacobi<T>(src, b, dst, N, pitch, lo, hi, omega, env_int("MGX_ROWS", 0), st, f->rows)) return MGX_ERR_INVALID;
             } else if (!launch_fused<T, SM>(K, src, b, dst, N, pitch, lo, hi, c0, c1, first - 1, last, f->row0 & 1, R, st, f->rows)) {
                 return MGX_ERR_INVALID;
             }
@@ -1481,9 +1497,9 @@ int mgx_slab_residual_sumsq(const mgx_slab* s, const void* u, const void* b, int
     if (row_lo < 1 || row_hi > s->rows - 1 || row_lo + s->row0 < 1 || row_hi + s->row0 > N || row_hi <= row_lo) return MGX_ERR_INVALID;
     const int rpc = env_int("MGX_ROWS", 0);
     if (s->dtype == MGX_DTYPE_F64)
-        launch_residual<double, 1>((const double*)u, (const double*)b, nullptr, 0, scratch, sum_dev, 1.0, N, pitch, row_lo, row_hi, rpc, (hipStream_t)stream);
+        launch_residual<double, 1>((const double*)u, (const double*)b, nullptr, 0, scratch, sum_dev, 1.0, N, pitch, row_lo, row_hi, rpc, (hipStream_t)stream, -1, s->rows);
     else
-        launch_residual<float, 1>((const float*)u, (const float*)b, nullptr, 0, scratch, sum_dev, 1.0, N, pitch, row_lo, row_hi, rpc, (hipStream_t)stream);
+        launch_residual<float, 1>((const float*)u, (const float*)b, nullptr, 0, scratch, sum_dev, 1.0, N, pitch, row_lo, row_hi, rpc, (hipStream_t)stream, -1, s->rows);
     return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_HIP;
 }
 

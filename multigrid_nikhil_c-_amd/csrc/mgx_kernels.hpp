@@ -27,8 +27,10 @@
 // keeping rolling row windows in registers, so each value is read from HBM once
 // per pass whatever the number of sweeps the pass performs.
 //
-// All loads are bounded by (N, pitch, allocation height): no kernel here can
-// address outside its arrays whatever the launch geometry.
+// Row bounds: the smoothers, the residual kernel and the fused / folded passes take the
+// allocation height (rows_alloc, or the slab's row window) and predicate every row they read
+// or write on it; k_restrict and k_prolong rely on the range checks of their launch wrappers'
+// callers (mgx_slab_restrict / mgx_slab_prolong validate every row they will touch).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -206,7 +208,7 @@ __device__ __forceinline__ float4 vscale(float c, const float4& v) { return make
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_jacobi(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
-         int N, long pitch, int row_lo, int row_hi, int R, int strips, int chunks, T c0, T c1)
+         int N, long pitch, int row_lo, int row_hi, int R, int strips, int chunks, T c0, T c1, int rows_alloc)
 {
     using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
@@ -219,19 +221,22 @@ k_jacobi(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ v
     const T* pb = rhs + c.col;
     T* po = vout + c.col;
 
-    V up = vload<V>(pv + (long)(r0 - 1) * pitch, c.ld);
-    V cur = vload<V>(pv + (long)r0 * pitch, c.ld);
-    V dn = vload<V>(pv + (long)(r0 + 1) * pitch, c.ld);
-    V bb = vload<V>(pb + (long)r0 * pitch, c.ld);
+    // a row is dereferenced only if the arrays hold it (0 <= row < rows_alloc): the predicates are
+    // wave-uniform scalar compares and cost nothing, and a caller's range can no longer fault
+    auto has = [&](int y) { return c.ld && y >= 0 && y < rows_alloc; };
+    V up = vload<V>(pv + (long)(r0 - 1) * pitch, has(r0 - 1));
+    V cur = vload<V>(pv + (long)r0 * pitch, has(r0));
+    V dn = vload<V>(pv + (long)(r0 + 1) * pitch, has(r0 + 1));
+    V bb = vload<V>(pb + (long)r0 * pitch, has(r0));
     for (int r = r0; r < r1; ++r) {
         // prefetch the next row before computing this one (r+2 <= row_hi+1 is
         // never dereferenced past row_hi: predicate on r + 1 < r1)
         const bool more = (r + 1 < r1);
-        const V dn2 = vload<V>(pv + (long)(r + 2) * pitch, c.ld && more);
-        const V bb2 = vload<V>(pb + (long)(r + 1) * pitch, c.ld && more);
+        const V dn2 = vload<V>(pv + (long)(r + 2) * pitch, has(r + 2) && more);
+        const V bb2 = vload<V>(pb + (long)(r + 1) * pitch, has(r + 1) && more);
         V o = jacobi_vec<T>(up, cur, dn, bb, c0, c1);
         if (c.vx == 0) o.x = (T)0;          // column 0 is the Dirichlet boundary
-        vstore<V>(po + (long)r * pitch, o, c.st);
+        vstore<V>(po + (long)r * pitch, o, c.st && r >= 0 && r < rows_alloc);
         up = cur; cur = dn; dn = dn2; bb = bb2;
     }
 }
@@ -244,7 +249,7 @@ k_jacobi(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ v
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_jacobi_rows(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
-              int N, long pitch, int row_lo, int row_hi, int strips, T c0, T c1)
+              int N, long pitch, int row_lo, int row_hi, int strips, T c0, T c1, int rows_alloc)
 {
     using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
@@ -253,13 +258,15 @@ k_jacobi_rows(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restric
     const Cols c = lane_cols<W>(t.strip, N, pitch);
     const int r = row_lo + t.chunk;
     const T* pv = vin + c.col + (long)r * pitch;
-    const V up = vload<V>(pv - pitch, c.ld);
-    const V cur = vload<V>(pv, c.ld);
-    const V dn = vload<V>(pv + pitch, c.ld);
-    const V bb = vload<V>(rhs + c.col + (long)r * pitch, c.ld);
+    // neighbour rows only where the arrays hold them (wave-uniform: r is a scalar)
+    const bool in = r >= 0 && r < rows_alloc;
+    const V up = vload<V>(pv - pitch, c.ld && r >= 1 && r <= rows_alloc);
+    const V cur = vload<V>(pv, c.ld && in);
+    const V dn = vload<V>(pv + pitch, c.ld && r >= -1 && r + 1 < rows_alloc);
+    const V bb = vload<V>(rhs + c.col + (long)r * pitch, c.ld && in);
     V o = jacobi_vec<T>(up, cur, dn, bb, c0, c1);
     if (c.vx == 0) o.x = (T)0;
-    vstore<V>(vout + c.col + (long)r * pitch, o, c.st);
+    vstore<V>(vout + c.col + (long)r * pitch, o, c.st && in);
 }
 
 // =============================================================================
@@ -573,7 +580,7 @@ template <typename T, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_residual(const T* __restrict__ vin, const T* __restrict__ rhs, void* __restrict__ out, long pitch_out,
            double* __restrict__ partial, double inv_scale,
-           int N, long pitch, int row_lo, int row_hi, int R, int strips, int chunks)
+           int N, long pitch, int row_lo, int row_hi, int R, int strips, int chunks, int rows_alloc)
 {
     using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
@@ -586,11 +593,12 @@ k_residual(const T* __restrict__ vin, const T* __restrict__ rhs, void* __restric
         const int r1 = min(r0 + R, row_hi);
         const T* pv = vin + c.col;
         const T* pb = rhs + c.col;
-        V up = vload<V>(pv + (long)(r0 - 1) * pitch, c.ld);
-        V cur = vload<V>(pv + (long)r0 * pitch, c.ld);
+        auto has = [&](int y) { return c.ld && y >= 0 && y < rows_alloc; };      // wave-uniform row test
+        V up = vload<V>(pv + (long)(r0 - 1) * pitch, has(r0 - 1));
+        V cur = vload<V>(pv + (long)r0 * pitch, has(r0));
         for (int r = r0; r < r1; ++r) {
-            const V dn = vload<V>(pv + (long)(r + 1) * pitch, c.ld);
-            const V bb = vload<V>(pb + (long)r * pitch, c.ld);
+            const V dn = vload<V>(pv + (long)(r + 1) * pitch, has(r + 1));
+            const V bb = vload<V>(pb + (long)r * pitch, has(r));
             V o = residual_vec(up, cur, dn, bb);
             mask_cols(o, c.col, N);
             if (MODE == 0) {

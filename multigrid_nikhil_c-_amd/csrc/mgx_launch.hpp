@@ -36,11 +36,15 @@ struct FuseCfg {
 };
 
 // ---- typed operator launches ----------------------------------------------------
+// rows_alloc: rows the arrays hold.  A sweep of rows [row_lo,row_hi) reads rows row_lo-1 .. row_hi:
+// ranges that would read outside the allocation are refused here, in one place for every caller
+// (and the kernels predicate their row loads on rows_alloc as well).
 template <typename T>
-void launch_jacobi(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
-                   double omega, int rpc, hipStream_t st)
+int launch_jacobi(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
+                  double omega, int rpc, hipStream_t st, int rows_alloc)
 {
-    if (row_hi <= row_lo) return;
+    if (row_hi <= row_lo) return MGX_OK;
+    if (row_lo < 1 || row_hi > rows_alloc - 1) return MGX_ERR_INVALID;
     // PS:127, 138-140: the float path evaluates the scalars in double from the
     // float omega and narrows them
     const T om = (T)omega;
@@ -50,12 +54,13 @@ void launch_jacobi(const T* vin, const T* b, T* vout, int N, long pitch, int row
         // default: one wave per row and strip (see k_jacobi_rows)
         const Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, 1);
         hipLaunchKernelGGL((k_jacobi_rows<T>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
-                           row_lo, row_hi, g.strips, c0, c1);
-        return;
+                           row_lo, row_hi, g.strips, c0, c1, rows_alloc);
+        return MGX_OK;
     }
     const Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, rpc);
     hipLaunchKernelGGL((k_jacobi<T>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
-                       row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1);
+                       row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, rows_alloc);
+    return MGX_OK;
 }
 
 template <typename T>
@@ -240,7 +245,8 @@ int smooth_block(int smoother, T* a, const T* rhs, T* b2, int N, long pitch, int
             const int rd_lo = std::max(lo - K, bl), rd_hi = std::min(hi + K - 1, bh);
             if (rd_lo < 0 || rd_hi > rows_alloc - 1) return MGX_ERR_INVALID;
             if (!rbgs && sw == 1) {
-                launch_jacobi<T>(src, rhs, dst, N, pitch, lo, hi, omega, rpc, st);
+                const int rc = launch_jacobi<T>(src, rhs, dst, N, pitch, lo, hi, omega, rpc, st, rows_alloc);
+                if (rc) return rc;
             } else if (rbgs && !allow_fuse) {
                 launch_rbgs<T>(src, rhs, dst, N, pitch, lo, hi, row_parity, bl, bh, rpc, st);
             } else {
@@ -415,10 +421,11 @@ template <typename T> long sumsq_blocks(int N, int rows, int rpc)
 }
 
 // sum (b - A u)^2 over rows -> sum_dev[0]; MODE 2 also writes scaled float residual
+// rows_alloc: rows the arrays hold (rows row_lo-1 .. row_hi are read; the kernel predicates on it)
 template <typename T, int MODE>
 void launch_residual(const T* v, const T* b, void* out, long pitch_out, double* partial, double* sum_dev,
                      double inv_scale, int N, long pitch, int row_lo, int row_hi, int rpc, hipStream_t st,
-                     long partial_cap = -1)
+                     long partial_cap, int rows_alloc)
 {
     Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, rpc);
     if (MODE != 0 && partial_cap >= 0 && g.blocks > partial_cap) {
@@ -427,7 +434,7 @@ void launch_residual(const T* v, const T* b, void* out, long pitch_out, double* 
         g = make_launch(N, VecOf<T>::W, row_hi - row_lo, R);
     }
     hipLaunchKernelGGL((k_residual<T, MODE>), dim3(g.blocks), dim3(kBlock), 0, st, v, b, out, pitch_out, partial,
-                       inv_scale, N, pitch, row_lo, row_hi, g.R, g.strips, g.chunks);
+                       inv_scale, N, pitch, row_lo, row_hi, g.R, g.strips, g.chunks, rows_alloc);
     if (MODE != 0)
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kReduceThreads), 0, st, partial, g.blocks, sum_dev);
 }

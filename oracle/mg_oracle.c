@@ -39,6 +39,11 @@ struct orc_solver {
     double* chol;        /* N x (bw+1), chol[i*(bw+1) + (i-j)] = L_ij */
     double* bottom_work; /* N */
     int chol_ready;
+    /* sine-transform bottom solve (ORC_BOTTOM_DST) */
+    double* dst_S;       /* n x n, S_jk = sqrt(2/(n+1)) sin(pi (j+1)(k+1)/(n+1)) */
+    double* dst_s;       /* n, 4 sin^2(pi (i+1) / (2 (n+1))) */
+    double* dst_w1;      /* n x n work */
+    double* dst_w2;
 };
 
 static inline int orc_n(int level) { return (1 << level) - 1; } /* PS:662-664 */
@@ -118,6 +123,61 @@ static void orc_chol_solve(orc_solver* s, double* x)
     }
 }
 
+/* ---- exact bottom solver, second method: type-I sine transform -------------
+ * The 5-point Dirichlet Laplacian is diagonalised by S (symmetric, S S = I):
+ * U = S ((S B S) ./ lambda) S, lambda_ij = s_i + s_j.  Mathematically the same x
+ * as the Cholesky solve; numerically it differs from it in the last bits.  This
+ * method performs the four n^3 products in double with one in-order accumulator
+ * per output (k = 0, 1, ... n-1, product then sum, no contraction) - the operation
+ * order of the device's bottom solver (csrc/mgx_bottom.hpp) - so that a float
+ * hierarchy rounds THE SAME fp64 value on both sides and float / mixed residual
+ * histories can be held to the fp64 tolerance.  Independent check of the method:
+ * tests compare it with the Cholesky solve (<= 1e-11). */
+static void orc_dst_init(orc_solver* s)
+{
+    const int n = orc_n(s->cfg.coarsest_level);
+    const size_t nn = (size_t)n * n;
+    s->dst_S = (double*)malloc(nn * sizeof(double));
+    s->dst_s = (double*)malloc((size_t)n * sizeof(double));
+    s->dst_w1 = (double*)malloc(nn * sizeof(double));
+    s->dst_w2 = (double*)malloc(nn * sizeof(double));
+    const long double pi = 3.14159265358979323846264338327950288L;
+    const long double norm = sqrtl(2.0L / (long double)(n + 1));
+    for (int i = 0; i < n; ++i) {
+        const long double a = sinl(pi * (long double)(i + 1) / (2.0L * (long double)(n + 1)));
+        s->dst_s[i] = (double)(4.0L * a * a);
+        for (int k = 0; k < n; ++k) {
+            /* argument reduced exactly before the sine */
+            const long m = ((long)(i + 1) * (long)(k + 1)) % (2L * (n + 1));
+            s->dst_S[(size_t)i * n + k] = (double)(norm * sinl(pi * (long double)m / (long double)(n + 1)));
+        }
+    }
+}
+
+/* C = A * B (n x n, row-major), in-order single accumulator; scale: C_ij /= (s_i + s_j) */
+static void orc_dst_gemm(const double* A, const double* B, double* C, const double* sc, int n, int scale)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc += A[(size_t)i * n + k] * B[(size_t)k * n + j];
+            if (scale) acc = acc / (sc[i] + sc[j]);
+            C[(size_t)i * n + j] = acc;
+        }
+}
+
+/* x (n x n doubles) <- A^-1 x */
+static void orc_dst_solve(orc_solver* s, double* x)
+{
+    if (!s->dst_S) orc_dst_init(s);
+    const int n = orc_n(s->cfg.coarsest_level);
+    orc_dst_gemm(s->dst_S, x, s->dst_w1, s->dst_s, n, 0);           /* S B          */
+    orc_dst_gemm(s->dst_w1, s->dst_S, s->dst_w2, s->dst_s, n, 1);   /* (S B S)./lam */
+    orc_dst_gemm(s->dst_S, s->dst_w2, s->dst_w1, s->dst_s, n, 0);   /* S (...)      */
+    orc_dst_gemm(s->dst_w1, s->dst_S, x, s->dst_s, n, 0);           /* ... S        */
+}
+
 /* ---- type-generic operators and schedules ------------------------------ */
 #define REAL double
 #define SUF(x) x##_f64
@@ -186,6 +246,7 @@ void orc_destroy(orc_solver* s)
     }
     free(s->chol);
     free(s->bottom_work);
+    free(s->dst_S); free(s->dst_s); free(s->dst_w1); free(s->dst_w2);
     free(s);
 }
 

@@ -46,7 +46,8 @@ enum { ORC_SMOOTHER_JACOBI = 0, ORC_SMOOTHER_RBGS = 1 };
 enum { ORC_DTYPE_F32 = 0, ORC_DTYPE_F64 = 1, ORC_DTYPE_MIXED = 2 };
 enum { ORC_SCHEDULE_V = 0, ORC_SCHEDULE_FMG = 1 };
 enum { ORC_RESTRICT_CONSISTENT = 0, ORC_RESTRICT_FW16 = 1 };
-enum { ORC_BOTTOM_EXACT = 0, ORC_BOTTOM_SMOOTH = 1 };
+enum { ORC_BOTTOM_EXACT = 0, ORC_BOTTOM_SMOOTH = 1,
+       ORC_BOTTOM_DST = 2 /* exact too: sine transform, in the device's operation order (mg_oracle.c) */ };
 
 /* Mirrors the reference's compile-time globals (PS:17-22, PS:127) as run-time
  * fields; same field order as mgx_config in include/mgx.h. */

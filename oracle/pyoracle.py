@@ -19,7 +19,7 @@ SMOOTHER_JACOBI, SMOOTHER_RBGS = 0, 1
 DTYPE_F32, DTYPE_F64, DTYPE_MIXED = 0, 1, 2
 SCHEDULE_V, SCHEDULE_FMG = 0, 1
 RESTRICT_CONSISTENT, RESTRICT_FW16 = 0, 1
-BOTTOM_EXACT, BOTTOM_SMOOTH = 0, 1
+BOTTOM_EXACT, BOTTOM_SMOOTH, BOTTOM_DST = 0, 1, 2
 
 
 class Config(C.Structure):

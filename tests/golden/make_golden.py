@@ -70,7 +70,12 @@ def histories():
                 b, u0 = po.rhs_constant(L), None
             else:
                 b, u0 = po.rhs_sine(L), po.fill_uniform(((1 << L) - 1,) * 2, 12345)
-            s = po.Solver(**cfg)
+            # float hierarchies: the oracle's sine-transform bottom mode (the device's direct method
+            # in the device's operation order), so both sides round the same fp64 bottom solution
+            ocfg = dict(cfg)
+            if ocfg.get("dtype", 1) != 1 and ocfg.get("bottom", 0) == 0:
+                ocfg["bottom"] = po.BOTTOM_DST
+            s = po.Solver(**ocfg)
             u, h = s.solve(b, u0, tol=1e-8, max_cycles=20)
             n = u.shape[0]
             out[f"{name}/{rhs}"] = dict(cfg=cfg, history=[float(x) for x in h],

@@ -107,3 +107,28 @@ def test_no_kernel_uses_scratch(tmp_path):
     sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
     assert len(sizes) > 50, "resource-usage remarks missing"
     assert max(sizes) == 0, f"{sum(1 for x in sizes if x)} kernels use scratch (max {max(sizes)} B/lane)"
+
+
+def test_reference_signatures_compile_as_the_reference_calls_them(tmp_path):
+    """include/mgx_reference_api.hpp: the free functions with the reference's own argument lists -
+    jacobirelaxation in its six-argument form exactly as PS:581 calls it, vcyclemultigrid /
+    fullmultigrid / restriction2d / interpolation2d as PS:617-645, 727 do (compile only: no GPU)."""
+    import subprocess
+
+    src = tmp_path / "calls.cpp"
+    src.write_text(
+        '#include "mgx_reference_api.hpp"\n'
+        'using namespace mgxref;\n'
+        'std::vector<float> like_ps(queue& q, matrix_elements_for_jacobi& a_h, std::vector<float>& vec_h, std::vector<float>& f_h) {\n'
+        '    const int mu1 = 10;\n'
+        '    vec_h = jacobirelaxation(q, a_h.a_lu_handle, a_h.size, vec_h, f_h, mu1);   // PS:581\n'
+        '    std::vector<float> r = restriction2d(f_h);                                 // PS:611, 641\n'
+        '    std::vector<float> p = interpolation2d(r);                                 // PS:620, 645\n'
+        '    std::vector<float> v = vcyclemultigrid(q, a_h, vec_h, f_h);                // PS:617\n'
+        '    return fullmultigrid(q, a_h, f_h);                                         // PS:727\n'
+        '}\n'
+        'static_assert(sizeof(matrix_handle_t) > 0, "");\n'
+        'int main() { return 0; }\n')
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

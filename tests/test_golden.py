@@ -33,7 +33,10 @@ def test_oracle_reproduces_history_fixtures(po):
             b, u0 = po.rhs_constant(L), None
         else:
             b, u0 = po.rhs_sine(L), po.fill_uniform(((1 << L) - 1,) * 2, 12345)
-        u, h = po.Solver(**cfg).solve(b, u0, tol=1e-8, max_cycles=20)
+        ocfg = dict(cfg)
+        if ocfg.get("dtype", 1) != 1 and ocfg.get("bottom", 0) == 0:
+            ocfg["bottom"] = po.BOTTOM_DST        # float hierarchies: the device's bottom method (make_golden.py)
+        u, h = po.Solver(**ocfg).solve(b, u0, tol=1e-8, max_cycles=20)
         assert len(h) == len(rec["history"]), key
         assert np.allclose(h, rec["history"], rtol=1e-12, atol=0), key
         assert abs(u[u.shape[0] // 2, u.shape[0] // 2] - rec["u_centre"]) <= 1e-13 * max(1.0, abs(rec["u_centre"])), key

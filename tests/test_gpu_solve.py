@@ -24,6 +24,19 @@ def hist_close(h, ref, rtol=HIST_TOL, floor_abs=0.0):
     return len(h) == len(ref) and bool(np.all(np.abs(h - ref) <= rtol * ref + max(HIST_FLOOR * ref[0], floor_abs)))
 
 
+def oracle_cfg(po, cfg):
+    """The oracle configuration that mirrors a device configuration.  For float hierarchies
+    (dtype F32 / MIXED) with an exact bottom solve the oracle uses its sine-transform bottom mode
+    (ORC_BOTTOM_DST: the device's direct method in the device's operation order), so that both
+    sides round THE SAME fp64 bottom solution to float; the float paths are then held to the same
+    1e-10 as double instead of the 1e-3 the Cholesky-vs-sine-transform last bit used to need.
+    Double hierarchies keep the Cholesky solve: an independent exact method, well inside 1e-10."""
+    c = dict(cfg)
+    if c.get("dtype", 1) != 1 and c.get("bottom", 0) == 0:
+        c["bottom"] = po.BOTTOM_DST
+    return c
+
+
 def problem(po, L, rhs):
     if rhs == "constant":
         return po.rhs_constant(L), None
@@ -47,17 +60,12 @@ def test_histories_match_committed_fixtures(pkg, po):
         b, u0 = problem(po, cfg["finest_level"], key.split("/")[1])
         st, h, u = run_gpu(pkg, cfg, b, u0)
         ref = np.array(rec["history"])
-        f32 = cfg.get("dtype", 1) == 0
-        # float histories stall at rounding level; compare what is above the floor
-        # float paths: the only device/oracle difference is the bottom solve's
-        # last bit (sine transform vs Cholesky), amplified where a float residual
-        # sits on its rounding floor
-        tol = 2e-3 if f32 else (1e-4 if cfg.get("dtype", 1) == 2 else HIST_TOL)
+        # float / mixed fixtures were written with the oracle's sine-transform bottom mode
+        # (oracle_cfg above): every history, float ones included, is held to 1e-10
         assert len(h) == len(ref), (key, len(h), len(ref))
-        keep = ref > (1e-4 * ref[0] if f32 else 0)
-        assert hist_close(h[keep], ref[keep], tol), (key, h, ref)
+        assert hist_close(h, ref), (key, h, ref)
         n = u.shape[0]
-        assert abs(u[n // 2, n // 2] - rec["u_centre"]) <= (1e-4 if f32 else 1e-9) * max(1.0, abs(rec["u_absmax"])), key
+        assert abs(u[n // 2, n // 2] - rec["u_centre"]) <= 1e-9 * max(1.0, abs(rec["u_absmax"])), key
 
 
 @pytest.mark.parametrize(
@@ -117,13 +125,12 @@ def test_mixed_precision_tracks_f64(pkg, po):
     cfg = dict(finest_level=10, coarsest_level=7, mu0=0, mu1=2, mu2=1, schedule=1, dtype=2)
     b = po.rhs_constant(10)
     st, h, u = run_gpu(pkg, cfg, b, None, max_cycles=25)
-    u_ref, h_ref = po.Solver(**cfg).solve(b, None, tol=1e-8, max_cycles=25)
-    # the inner cycle is fp32 and bit-identical to the oracle's except for the last
-    # bit of the bottom solve; the fp32 FMG result sits on the float rounding floor
-    # (D11), where that bit is visible at the 1e-4 level in the residual norm
-    assert hist_close(h, h_ref, 1e-3), (h, h_ref)
+    u_ref, h_ref = po.Solver(**oracle_cfg(po, cfg)).solve(b, None, tol=1e-8, max_cycles=25)
+    # the inner cycle is fp32 and performs the oracle's operations in the oracle's order, the
+    # bottom solve included (ORC_BOTTOM_DST): same tolerance as double
+    assert hist_close(h, h_ref), (h, h_ref)
     assert h[-1] <= 1e-8 * h[0]
-    assert np.max(np.abs(u - u_ref)) <= 1e-9 * np.max(np.abs(u_ref))
+    assert np.max(np.abs(u - u_ref)) <= 1e-12 * np.max(np.abs(u_ref))
     # and the same iteration counts as full double (SURVEY §6.2 last row)
     cfg64 = dict(cfg, dtype=1)
     _, h64 = po.Solver(**cfg64).solve(b, None, tol=1e-8, max_cycles=25)
@@ -255,7 +262,9 @@ def test_tuning_knobs_never_change_a_bit(pkg, po, monkeypatch, smoother):
 def test_seeded_fuzz_of_configurations_against_the_oracle(pkg, po, monkeypatch):
     """40 random configurations (fixed seed): levels 4..10, 0..6 sweeps, both smoothers, f64 and
     mixed, V and FMG, both restriction weights and bottom modes.  Every history must match the
-    oracle's (1e-10 relative above the rounding floor for f64; 1e-3 for the float inner cycle)."""
+    oracle's to 1e-10 relative, double and mixed alike (oracle_cfg: same bottom method for the
+    float inner cycle); the absolute rounding floor of an exact solve applies to one-level
+    hierarchies only."""
     rng = np.random.default_rng(20261004)
     for case in range(40):
         finest = int(rng.integers(6, 11))
@@ -277,15 +286,16 @@ def test_seeded_fuzz_of_configurations_against_the_oracle(pkg, po, monkeypatch):
         else:
             monkeypatch.delenv("MGX_TILE_MAX_N", raising=False)
         st, h, u = run_gpu(pkg, cfg, b, u0, tol=1e-9, max_cycles=6)
-        u_ref, h_ref = po.Solver(**cfg).solve(b, u0, tol=1e-9, max_cycles=6)
+        u_ref, h_ref = po.Solver(**oracle_cfg(po, cfg)).solve(b, u0, tol=1e-9, max_cycles=6)
         assert len(h) == len(h_ref), (case, cfg, h, h_ref)
-        rtol = 1e-3 if cfg["dtype"] == 2 else HIST_TOL
         scale = max(np.max(np.abs(u_ref)), 1e-300)
         # rounding floor of a double residual: eps * (|b| + 8|u|) per entry, n entries per row and
-        # column in the 2-norm; it is what is left after an exact solve (one-level hierarchies)
-        floor = 32 * np.finfo(np.float64).eps * scale * n
-        assert hist_close(h, h_ref, rtol, floor), (case, cfg, h, h_ref)
-        assert np.max(np.abs(u - u_ref)) <= (1e-7 if cfg["dtype"] == 2 else 1e-10) * scale, (case, cfg)
+        # column in the 2-norm; it is what is left after an exact solve, i.e. on a one-level
+        # hierarchy, where the two exact methods (Cholesky, sine transform) leave different noise
+        one_level = (finest == coarsest and cfg["bottom"] == 0)
+        floor = 32 * np.finfo(np.float64).eps * scale * n if one_level else 0.0
+        assert hist_close(h, h_ref, HIST_TOL, floor), (case, cfg, h, h_ref)
+        assert np.max(np.abs(u - u_ref)) <= 1e-10 * scale, (case, cfg)
 
 
 GRAPH_CASES = [
@@ -360,10 +370,9 @@ def test_mixed_update_and_residual_in_one_pass_is_bit_identical(pkg, po, monkeyp
     assert out["0"][2] == out["1"][2]
     assert np.array_equal(out["0"][0], out["1"][0])
     assert np.array_equal(out["0"][1], out["1"][1])
-    # the float inner cycle follows the oracle's to 1e-3 per cycle over the first cycles (the exact
-    # bottom solves differ in the last float digit and the difference compounds afterwards)
-    _, h_ref = po.Solver(**cfg).solve(b, u0, tol=1e-10, max_cycles=25)
-    assert hist_close(out["1"][0][:6], h_ref[:6], 1e-3)
+    # and the whole history follows the oracle's (same bottom method: oracle_cfg) to 1e-10
+    _, h_ref = po.Solver(**oracle_cfg(po, cfg)).solve(b, u0, tol=1e-10, max_cycles=25)
+    assert hist_close(out["1"][0], h_ref)
 
 
 FULL_SIZE = [

@@ -164,3 +164,26 @@ def test_cpu_baselines_agree_with_the_oracle_sweep(po):
         _, a = po.baseline_jacobi("csr", v, f, 4)
         _, b = po.baseline_jacobi("omp", v, f, 4, threads=2)
         assert np.max(np.abs(a - ref)) < tol and np.max(np.abs(b - ref)) < tol
+
+
+def test_sine_transform_bottom_mode_agrees_with_cholesky(po):
+    """ORC_BOTTOM_DST (the device's direct method in the device's operation order, used when a
+    float hierarchy is compared) and the banded Cholesky solve are two exact methods: same x to
+    rounding, and both satisfy A x = b."""
+    import numpy as np
+
+    for level in (3, 6, 7):
+        n = (1 << level) - 1
+        b = np.random.default_rng(level).uniform(-1, 1, (n, n))
+        xs = {}
+        for mode in (po.BOTTOM_EXACT, po.BOTTOM_DST):
+            s = po.Solver(finest_level=level, coarsest_level=level, bottom=mode)
+            xs[mode] = s.bottom_solve(b)
+            r = po.residual(xs[mode], b)
+            assert np.max(np.abs(r)) <= 1e-12 * np.max(np.abs(b)) * n
+        assert np.max(np.abs(xs[po.BOTTOM_EXACT] - xs[po.BOTTOM_DST])) <= 1e-11 * np.max(np.abs(xs[po.BOTTOM_EXACT]))
+        # float entry point: rounds the fp64 solution once
+        s32 = po.Solver(finest_level=level, coarsest_level=level, bottom=po.BOTTOM_DST, dtype=po.DTYPE_F32)
+        x32 = s32.bottom_solve(b.astype(np.float32))
+        s64 = po.Solver(finest_level=level, coarsest_level=level, bottom=po.BOTTOM_DST)
+        assert np.array_equal(x32, s64.bottom_solve(b.astype(np.float32).astype(np.float64)).astype(np.float32))

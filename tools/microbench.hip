@@ -194,7 +194,7 @@ void run_level(int level, int iters)
         const Launch g = make_launch(N, W, N - 1, R);
         T* src = u; T* dst = tmp;
         float ms = tm.run([&] {
-            hipLaunchKernelGGL((k_jacobi<T>), dim3(g.blocks), dim3(kBlock), 0, 0, src, b, dst, N, pitch, 1, N, g.R, g.strips, g.chunks, c0, c1);
+            hipLaunchKernelGGL((k_jacobi<T>), dim3(g.blocks), dim3(kBlock), 0, 0, src, b, dst, N, pitch, 1, N, g.R, g.strips, g.chunks, c0, c1, N + 1);
             std::swap(src, dst);
         }, 3, iters);
         char nm[64]; snprintf(nm, sizeof nm, "jacobi A (62-lane) R=%d blocks=%d", R, g.blocks);
@@ -319,7 +319,7 @@ void run_level(int level, int iters)
         double* partial; double* sum;
         CK(hipMalloc(&partial, (g.blocks + 8) * sizeof(double))); CK(hipMalloc(&sum, 8));
         float ms = tm.run([&] {
-            hipLaunchKernelGGL((k_residual<T, 1>), dim3(g.blocks), dim3(kBlock), 0, 0, u, b, (void*)nullptr, 0L, partial, 1.0, N, pitch, 1, N, g.R, g.strips, g.chunks);
+            hipLaunchKernelGGL((k_residual<T, 1>), dim3(g.blocks), dim3(kBlock), 0, 0, u, b, (void*)nullptr, 0L, partial, 1.0, N, pitch, 1, N, g.R, g.strips, g.chunks, N + 1);
             hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kReduceThreads), 0, 0, partial, g.blocks, sum);
         }, 3, iters);
         report("residual norm (2 launches)", ms, 2.0 * sizeof(T));
