@@ -47,6 +47,7 @@ enum { MGX_DTYPE_F32 = 0, MGX_DTYPE_F64 = 1, MGX_DTYPE_MIXED = 2 };
 enum { MGX_SCHEDULE_V = 0, MGX_SCHEDULE_FMG = 1 };
 enum { MGX_RESTRICT_CONSISTENT = 0, MGX_RESTRICT_FW16 = 1 };
 enum { MGX_BOTTOM_EXACT = 0, MGX_BOTTOM_SMOOTH = 1 };
+#define MGX_MAX_GPUS 16
 
 /* The reference's compile-time globals as run-time fields.
  * PS:17-22 (finest_level, coarsest_level, mu0, mu1, mu2), PS:127 (omega);
@@ -64,8 +65,19 @@ typedef struct {
     int schedule;         /* MGX_SCHEDULE_*  (PS:727 calls fullmultigrid = FMG) */
     int restrict_mode;    /* MGX_RESTRICT_*   */
     int bottom;           /* MGX_BOTTOM_*    (EXACT: MF:137-139; SMOOTH: PS:581-587, D8) */
-    int device;           /* HIP device ordinal */
+    int device;           /* HIP device ordinal (n_gpus <= 1) */
     int profile;          /* 1: record HIP events around each operator class */
+    /* ---- multi-GPU (the reference has one sycl::queue, PS:659) -------------
+     * n_gpus > 1: the levels above cut_level are split into n_gpus row slabs, slab g on device
+     * devices[g]; one stream pair per slab, halo rows moved device to device between the
+     * smoothing blocks (hipMemcpyPeerAsync inside one process, RCCL send/recv between the
+     * processes of mgx_create_rank), levels <= cut_level solved redundantly per device
+     * ("the bottom solve stays on one GPU").  Several slabs may share a device (devices[g] all 0
+     * runs the whole slab plan on one GPU: how the 1-GPU tests check n_gpus = 2, 4, 8 bit for bit
+     * against n_gpus = 1).  Multi-GPU handles run V-cycles (schedule V), dtype F64 or F32. */
+    int n_gpus;           /* 0 or 1: single GPU */
+    int cut_level;        /* 0: chosen from the grid and n_gpus */
+    int devices[MGX_MAX_GPUS];   /* -1 entries: slab g on device g modulo the device count */
 } mgx_config;
 
 typedef struct mgx_solver* mgx_handle;
@@ -269,6 +281,90 @@ MGX_API int mgx_slab_prolong(const mgx_slab* f, void* u, const mgx_slab* c, cons
 MGX_API int mgx_slab_residual_sumsq(const mgx_slab* s, const void* u, const void* b,
                                     int row_lo, int row_hi, double* scratch, double* sum_dev, void* stream);
 MGX_API long mgx_slab_scratch_doubles(const mgx_slab* s);
+
+
+/* =============================================================================
+ * Multi-GPU: the slab plan as data, ranks, transports.
+ *
+ * mgx_create with cfg.n_gpus > 1 drives every slab from ONE process (one host thread, a stream
+ * pair per device).  mgx_create_rank is the one-process-per-GPU form (torch.distributed.run /
+ * mpirun launch `world` processes): this process owns slab `rank` and talks to its neighbours
+ * through `transport` - NULL selects the built-in RCCL transport, which needs the 128-byte
+ * ncclUniqueId of rank 0 (mgx_rccl_unique_id) handed to every rank by the launcher.
+ * On such handles: mgx_set_rhs / mgx_set_guess / mgx_get_solution (whole-grid host vectors; each
+ * slab takes / returns its rows), mgx_fill_rhs, mgx_fill_guess_random, mgx_residual_norm (finest
+ * level), mgx_vcycle (finest level), mgx_solve, mgx_synchronize, mgx_destroy; everything else
+ * returns MGX_ERR_STATE.
+ * ===========================================================================*/
+enum {
+    MGX_DOP_EXCHANGE = 1,       /* fill `depth` halo rows of `which` (U / B) of `level` from both neighbours */
+    MGX_DOP_ZERO_U = 2,         /* zero the coarse guess slab of `level` (PS:613) */
+    MGX_DOP_CYCLE = 3,          /* mgx_slab_cycle: mu sweeps on [row_lo,row_hi) with folded transfers (pre / post) */
+    MGX_DOP_SMOOTH = 4,         /* mgx_slab_jacobi / _rbgs, shrink = 1 */
+    MGX_DOP_RESTRICT = 5,       /* mgx_slab_restrict, fused residual, coarse rows [crow_lo,crow_hi) */
+    MGX_DOP_PROLONG = 6,        /* mgx_slab_prolong, add = 1, fine rows [row_lo,row_hi) */
+    MGX_DOP_GATHER_CUT = 7,     /* all-gather the slabs' shares of the cut level's right-hand side */
+    MGX_DOP_COARSE = 8,         /* one V-cycle from e = 0 on levels cut..coarsest (replicated) */
+    MGX_DOP_SUMSQ = 9,          /* sum of (b - A u)^2 over rows [row_lo,row_hi) of the finest level */
+    MGX_DOP_ALLREDUCE_NORM = 10 /* sum the slabs' sums of squares; the norm is its square root */
+};
+typedef struct {
+    int op, level;
+    int which, depth;           /* EXCHANGE */
+    int row_lo, row_hi, mu;     /* CYCLE / SMOOTH / PROLONG / SUMSQ: local rows of the slab of `level` */
+    int pre;                    /* CYCLE: 1 = the input is u + P e (PS:620-624) */
+    int post;                   /* CYCLE: 1 = restrict the residual of the result (PS:604-611), 2 = sum its squares */
+    int crow_lo, crow_hi;       /* CYCLE post 1 / RESTRICT: local coarse rows produced */
+    int coarse_is_cut;          /* the level below is the cut level (this slab's share / the gathered grid) */
+} mgx_dist_op;
+typedef struct {
+    int level, N;               /* N = 2^level: rows 0..N */
+    int own_lo, own_hi;         /* global rows owned: [own_lo, own_hi) */
+    int halo;                   /* halo rows allocated per side */
+    int row0, rows;             /* global row of local row 0, rows allocated */
+} mgx_dist_level;
+
+/* The plan of slab `g` of `n_slabs` for cfg (cfg.n_gpus is ignored, cfg.cut_level 0 = default):
+ * pure host logic, no device needed - the CPU tests run these plans over numpy and gloo. */
+typedef struct mgx_dist_planner* mgx_plan_handle;
+MGX_API int mgx_plan_create(const mgx_config* cfg, int n_slabs, int g, int fold, int deep, mgx_plan_handle* out);
+MGX_API int mgx_plan_destroy(mgx_plan_handle p);
+MGX_API const char* mgx_plan_last_error(void);
+MGX_API int mgx_plan_cut_level(mgx_plan_handle p);
+/* geometry of the slab of `level` (cut < level <= finest) */
+MGX_API int mgx_plan_level(mgx_plan_handle p, int level, mgx_dist_level* out);
+/* this slab's share of the cut level: rows [row0, row0 + rows) */
+MGX_API int mgx_plan_cut_share(mgx_plan_handle p, int* row0, int* rows);
+/* the caller refilled u of the finest level: all rows incl. halos (all_rows = 1) or owned rows only */
+MGX_API int mgx_plan_guess_set(mgx_plan_handle p, int all_rows);
+/* operations of one V-cycle / of the residual norm, in order; returns the count (< 0: cap too small) */
+MGX_API int mgx_plan_vcycle(mgx_plan_handle p, mgx_dist_op* ops, int cap);
+MGX_API int mgx_plan_norm(mgx_plan_handle p, mgx_dist_op* ops, int cap);
+
+/* what moves between slabs of different processes */
+typedef struct { int send; int peer; void* ptr; size_t bytes; } mgx_xfer;   /* send = 1: ptr -> peer; 0: peer -> ptr */
+typedef struct {
+    void* ctx;
+    /* every transfer of one halo exchange; device pointers; must be complete, or ordered on `stream`
+     * (a hipStream_t), when the call returns */
+    int (*sendrecv)(void* ctx, int n, const mgx_xfer* x, void* stream);
+    /* recv[r * bytes .. ) = rank r's send[0 .. bytes); device pointers, same completion rule */
+    int (*allgather)(void* ctx, const void* send, void* recv, size_t bytes, void* stream);
+    /* *value = sum over ranks of *value (host double) */
+    int (*allreduce_sum)(void* ctx, double* value);
+} mgx_transport;
+/* 128 bytes identifying a new RCCL communicator (ncclGetUniqueId); rank 0 calls it, the launcher
+ * distributes the bytes */
+MGX_API int mgx_rccl_unique_id(void* out128);
+/* One rank of `world` (one process per GPU).  transport = NULL: built-in RCCL (rccl_id = the 128
+ * bytes of mgx_rccl_unique_id from rank 0); otherwise the caller's transport (rccl_id ignored). */
+MGX_API int mgx_create_rank(const mgx_config* cfg, int rank, int world, const void* rccl_id,
+                            const mgx_transport* transport, mgx_handle* out);
+/* number of halo exchanges a multi-GPU handle has performed (tests: communication plan) */
+MGX_API long mgx_dist_exchanges(mgx_handle h);
+/* plain copies for callers that implement a transport without a HIP binding of their own */
+MGX_API int mgx_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+MGX_API int mgx_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

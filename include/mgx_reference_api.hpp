@@ -70,6 +70,8 @@ struct parameters {
     int bottom = MGX_BOTTOM_EXACT;
     float f = 4.0f;                             // PS:123
     int device = 0;
+    int n_gpus = 1;                             // PS:659 has one queue; > 1: row slabs over that many GPUs
+    int devices[MGX_MAX_GPUS] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 };
 
 template <typename Real> struct hierarchy {
@@ -111,6 +113,9 @@ inline std::vector<matrix_elements_for_jacobi>& build_hierarchy(const parameters
     cfg.restrict_mode = prm.restrict_mode;
     cfg.bottom = prm.bottom;
     cfg.device = prm.device;
+    cfg.n_gpus = prm.n_gpus;
+    for (int i = 0; i < MGX_MAX_GPUS; ++i) cfg.devices[i] = prm.devices[i];
+    if (prm.n_gpus > 1) cfg.schedule = MGX_SCHEDULE_V;        // multi-GPU handles run V-cycles
     check(mgx_create(&cfg, &H.handle), nullptr, "mgx_create");
     H.jacobi_matrices.assign(prm.finest_level - prm.coarsest_level + 1, {});
     for (int level = prm.coarsest_level; level <= prm.finest_level; ++level) {   // PS:661

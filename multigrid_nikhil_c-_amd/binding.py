@@ -37,7 +37,13 @@ EXPORTS = [
     "mgx_profile_get", "mgx_time_smoother", "mgx_synchronize", "mgx_graphs_cached", "mgx_slab_cycle", "mgx_level_pitch",
     "mgx_slab_jacobi", "mgx_slab_rbgs", "mgx_slab_restrict", "mgx_slab_prolong",
     "mgx_slab_residual_sumsq", "mgx_slab_scratch_doubles",
+    "mgx_plan_create", "mgx_plan_destroy", "mgx_plan_last_error", "mgx_plan_cut_level", "mgx_plan_level",
+    "mgx_plan_cut_share", "mgx_plan_guess_set", "mgx_plan_vcycle", "mgx_plan_norm", "mgx_rccl_unique_id",
+    "mgx_create_rank", "mgx_dist_exchanges", "mgx_memcpy_d2h", "mgx_memcpy_h2d",
 ]
+MAX_GPUS = 16
+(DOP_EXCHANGE, DOP_ZERO_U, DOP_CYCLE, DOP_SMOOTH, DOP_RESTRICT, DOP_PROLONG, DOP_GATHER_CUT, DOP_COARSE, DOP_SUMSQ,
+ DOP_ALLREDUCE_NORM) = range(1, 11)
 
 
 class Config(C.Structure):
@@ -48,6 +54,7 @@ class Config(C.Structure):
         ("smoother", C.c_int), ("dtype", C.c_int), ("schedule", C.c_int),
         ("restrict_mode", C.c_int), ("bottom", C.c_int),
         ("device", C.c_int), ("profile", C.c_int),
+        ("n_gpus", C.c_int), ("cut_level", C.c_int), ("devices", C.c_int * MAX_GPUS),
     ]
 
 
@@ -68,8 +75,42 @@ class Slab(C.Structure):
     _fields_ = [("level", C.c_int), ("dtype", C.c_int), ("rows", C.c_int), ("row0", C.c_int)]
 
 
+class DistOp(C.Structure):
+    """mgx_dist_op: one operation of a slab plan"""
+    _fields_ = [("op", C.c_int), ("level", C.c_int), ("which", C.c_int), ("depth", C.c_int),
+                ("row_lo", C.c_int), ("row_hi", C.c_int), ("mu", C.c_int), ("pre", C.c_int), ("post", C.c_int),
+                ("crow_lo", C.c_int), ("crow_hi", C.c_int), ("coarse_is_cut", C.c_int)]
+
+
+class DistLevel(C.Structure):
+    _fields_ = [("level", C.c_int), ("N", C.c_int), ("own_lo", C.c_int), ("own_hi", C.c_int), ("halo", C.c_int),
+                ("row0", C.c_int), ("rows", C.c_int)]
+
+
+class Xfer(C.Structure):
+    _fields_ = [("send", C.c_int), ("peer", C.c_int), ("ptr", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(Xfer), C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
+
+
+class Transport(C.Structure):
+    """mgx_transport: what moves between the slabs of different processes"""
+    _fields_ = [("ctx", C.c_void_p), ("sendrecv", SENDRECV_FN), ("allgather", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN)]
+
+
 class MgxError(RuntimeError):
     pass
+
+
+def rccl_unique_id() -> bytes:
+    """128 bytes naming a new RCCL communicator (rank 0 calls it, the launcher hands them to every rank)"""
+    buf = C.create_string_buffer(128)
+    if lib().mgx_rccl_unique_id(buf) != 0:
+        raise MgxError("mgx_rccl_unique_id failed")
+    return buf.raw
 
 
 _lib = None
@@ -125,6 +166,21 @@ def lib() -> C.CDLL:
     L.mgx_slab_residual_sumsq.argtypes = [sp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.mgx_slab_scratch_doubles.argtypes = [sp]
     L.mgx_slab_scratch_doubles.restype = C.c_long
+    L.mgx_plan_create.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.mgx_plan_destroy.argtypes = [vp]
+    L.mgx_plan_last_error.restype = C.c_char_p
+    L.mgx_plan_cut_level.argtypes = [vp]
+    L.mgx_plan_level.argtypes = [vp, C.c_int, C.POINTER(DistLevel)]
+    L.mgx_plan_cut_share.argtypes = [vp, ip, ip]
+    L.mgx_plan_guess_set.argtypes = [vp, C.c_int]
+    L.mgx_plan_vcycle.argtypes = [vp, C.POINTER(DistOp), C.c_int]
+    L.mgx_plan_norm.argtypes = [vp, C.POINTER(DistOp), C.c_int]
+    L.mgx_rccl_unique_id.argtypes = [vp]
+    L.mgx_create_rank.argtypes = [C.POINTER(Config), C.c_int, C.c_int, vp, C.POINTER(Transport), C.POINTER(vp)]
+    L.mgx_dist_exchanges.argtypes = [vp]
+    L.mgx_dist_exchanges.restype = C.c_long
+    L.mgx_memcpy_d2h.argtypes = [vp, vp, C.c_size_t, vp]
+    L.mgx_memcpy_h2d.argtypes = [vp, vp, C.c_size_t, vp]
     _lib = L
     return L
 
@@ -140,8 +196,61 @@ def default_config(**kw) -> Config:
     for k, v in kw.items():
         if not hasattr(c, k):
             raise TypeError(f"unknown mgx_config field {k!r}")
-        setattr(c, k, v)
+        if k == "devices":
+            for i, d in enumerate(v):
+                c.devices[i] = int(d)
+        else:
+            setattr(c, k, v)
     return c
+
+
+class Plan:
+    """mgx_plan_*: the multi-GPU V-cycle of slab `g` of `n_slabs` as a list of operations (host
+    logic only: usable without a GPU; the CPU tests execute these plans over numpy and gloo)"""
+
+    def __init__(self, n_slabs, g, fold=True, deep=True, **cfg):
+        self.cfg = default_config(**cfg)
+        self._h = C.c_void_p()
+        st = lib().mgx_plan_create(C.byref(self.cfg), n_slabs, g, 1 if fold else 0, 1 if deep else 0, C.byref(self._h))
+        if st != 0:
+            raise MgxError(f"mgx_plan_create: {lib().mgx_plan_last_error().decode()}")
+        self.cut = lib().mgx_plan_cut_level(self._h)
+        r0, rows = C.c_int(), C.c_int()
+        lib().mgx_plan_cut_share(self._h, C.byref(r0), C.byref(rows))
+        self.c_row0, self.c_rows = r0.value, rows.value
+
+    def level(self, level):
+        g = DistLevel()
+        if lib().mgx_plan_level(self._h, level, C.byref(g)) != 0:
+            raise MgxError("mgx_plan_level: level is not distributed")
+        return g
+
+    def guess_set(self, all_rows=True):
+        lib().mgx_plan_guess_set(self._h, 1 if all_rows else 0)
+
+    def _emit(self, fn):
+        buf = (DistOp * 256)()
+        n = fn(self._h, buf, 256)
+        if n < 0:
+            raise MgxError("plan longer than 256 operations")
+        return [buf[i] for i in range(n)]
+
+    def vcycle(self):
+        return self._emit(lib().mgx_plan_vcycle)
+
+    def norm(self):
+        return self._emit(lib().mgx_plan_norm)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mgx_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Multigrid:
@@ -149,14 +258,33 @@ class Multigrid:
     schedules that act on it.  Vectors cross this boundary as 2-D numpy arrays
     in the reference's interior-only n x n layout (PS:227, 291)."""
 
-    def __init__(self, **cfg):
+    def __init__(self, _rank=None, **cfg):
         self.cfg = default_config(**cfg)
         self._h = C.c_void_p()
-        st = lib().mgx_create(C.byref(self.cfg), C.byref(self._h))
+        self._keep = None
+        if _rank is None:
+            st = lib().mgx_create(C.byref(self.cfg), C.byref(self._h))
+        else:
+            rank, world, rccl_id, transport = _rank
+            self._keep = (rccl_id, transport)              # callbacks / id bytes must outlive the handle
+            st = lib().mgx_create_rank(C.byref(self.cfg), rank, world, rccl_id,
+                                       C.byref(transport) if transport is not None else None, C.byref(self._h))
         if st != 0:
             msg = lib().mgx_last_error(None).decode()
             self._h = C.c_void_p()
             raise MgxError(f"mgx_create: {lib().mgx_status_string(st).decode()}: {msg}")
+
+    @classmethod
+    def rank(cls, rank, world, rccl_id=None, transport=None, **cfg):
+        """mgx_create_rank: this process owns slab `rank` of `world` (one process per GPU).
+        rccl_id: the 128 bytes of rccl_unique_id() from rank 0 (built-in RCCL transport), or
+        transport: a Transport of the caller's."""
+        idbuf = C.create_string_buffer(bytes(rccl_id), 128) if rccl_id is not None else None
+        return cls(_rank=(rank, world, idbuf, transport), **cfg)
+
+    def exchanges(self):
+        """halo exchanges a multi-GPU handle has performed"""
+        return int(lib().mgx_dist_exchanges(self._h))
 
     # -- plumbing --------------------------------------------------------------
     def _chk(self, st, what):
@@ -226,6 +354,13 @@ class Multigrid:
 
     def get_solution(self):
         return self.get_level(self.cfg.finest_level, VEC_U)
+
+    def get_solution_into(self, a):
+        """finest-level U into the caller's n x n array (a rank handle of a multi-GPU job fills the
+        rows it owns and leaves the others untouched)"""
+        assert a.flags["C_CONTIGUOUS"] and a.dtype == self.level_dtype(self.cfg.finest_level)
+        self._chk(lib().mgx_get_solution(self._h, a.ctypes.data, a.size), "mgx_get_solution")
+        return a
 
     def fill_rhs(self, kind=0, f=4.0):
         self._chk(lib().mgx_fill_rhs(self._h, kind, f), "mgx_fill_rhs")

@@ -14,6 +14,7 @@
 #include "mgx_bottom.hpp"
 #include "mgx_kernels.hpp"
 #include "mgx_launch.hpp"
+#include "mgx_dist_plan.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -78,6 +79,7 @@ struct mgx_solver {
     std::vector<CycleGraph> graphs;
     int use_graph = 1;              // MGX_GRAPH
     int mixed_fuse = 1;             // mixed precision: u += s e and the residual in one pass (MGX_MIXED_FUSE)
+    struct mgx_dist* dist = nullptr; // multi-GPU handle (cfg.n_gpus > 1 / mgx_create_rank): mgx_dist.hpp; no levels of its own
 
     int fail(int code, const std::string& m) { err = m; return code; }
 };
@@ -730,6 +732,12 @@ void fold_ring(std::vector<T>& b, const T* ring, size_t n)
 }
 } // namespace
 
+#include "mgx_dist.hpp"
+
+// entry points that make no sense on a multi-GPU handle
+#define NO_DIST(s)                                                                        \
+    if ((s)->dist) return (s)->fail(MGX_ERR_STATE, "not available on a multi-GPU handle (see mgx.h, Multi-GPU)");
+
 // =====================================================================================
 // C-ABI
 // =====================================================================================
@@ -751,6 +759,9 @@ int mgx_config_default(mgx_config* c)
     c->bottom = MGX_BOTTOM_EXACT;
     c->device = 0;
     c->profile = 0;
+    c->n_gpus = 0;             // PS:659: one queue
+    c->cut_level = 0;
+    for (int i = 0; i < MGX_MAX_GPUS; ++i) c->devices[i] = -1;
     return MGX_OK;
 }
 
@@ -795,6 +806,7 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
         g_create_error = "exact bottom solve supports coarsest_level <= 8";
         return MGX_ERR_INVALID;
     }
+    if (cfg->n_gpus > 1) return mgx_create_rank(cfg, -1, 1, nullptr, nullptr, out);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
         g_create_error = "no usable HIP device (libmgx has no CPU fallback)";
@@ -853,6 +865,7 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
 int mgx_destroy(mgx_handle s)
 {
     if (!s) return MGX_OK;
+    if (s->dist) { dist_free(s->dist); s->dist = nullptr; }
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (auto& l : s->lv) free_level(l);
     free_level(s->fine64);
@@ -871,6 +884,11 @@ int mgx_destroy(mgx_handle s)
 int mgx_graphs_cached(mgx_handle s)
 {
     if (!s) return MGX_ERR_INVALID;
+    if (s->dist) {
+        // the replicated coarse levels of the first local slab replay their cycle from a graph
+        mgx_handle c = s->dist->slabs[0].coarse;
+        return (c && c->use_graph) ? (int)c->graphs.size() : -1;
+    }
     if (!s->use_graph || s->cfg.profile || s->mixed) return -1;
     return (int)s->graphs.size();
 }
@@ -878,6 +896,7 @@ int mgx_graphs_cached(mgx_handle s)
 int mgx_synchronize(mgx_handle s)
 {
     if (!s) return MGX_ERR_INVALID;
+    if (s->dist) return dist_sync(s, s->dist);
     HIPCHK(s, hipStreamSynchronize(s->stream));
     return MGX_OK;
 }
@@ -887,6 +906,11 @@ int mgx_set_level(mgx_handle s, int level, int which, const void* src, size_t co
 {
     if (!s || !src) return MGX_ERR_INVALID;
     if (!level_ok(s, level)) return s->fail(MGX_ERR_INVALID, "level out of range");
+    if (s->dist) {
+        if (level != s->cfg.finest_level || (which != MGX_VEC_U && which != MGX_VEC_B))
+            return s->fail(MGX_ERR_STATE, "multi-GPU handles exchange U and B of the finest level only");
+        return dist_set(s, s->dist, which, src, count);
+    }
     void* grid = nullptr;
     Level* l = pick(s, level, which, &grid);
     if (which == MGX_VEC_R) {
@@ -902,6 +926,11 @@ int mgx_get_level(mgx_handle s, int level, int which, void* dst, size_t count)
 {
     if (!s || !dst) return MGX_ERR_INVALID;
     if (!level_ok(s, level)) return s->fail(MGX_ERR_INVALID, "level out of range");
+    if (s->dist) {
+        if (level != s->cfg.finest_level || (which != MGX_VEC_U && which != MGX_VEC_B))
+            return s->fail(MGX_ERR_STATE, "multi-GPU handles exchange U and B of the finest level only");
+        return dist_get(s, s->dist, which, dst, count);
+    }
     void* grid = nullptr;
     Level* l = pick(s, level, which, &grid);
     if (!grid) return s->fail(MGX_ERR_STATE, "vector not available (call mgx_residual first for MGX_VEC_R)");
@@ -911,6 +940,7 @@ int mgx_get_level(mgx_handle s, int level, int which, void* dst, size_t count)
 int mgx_set_level_device(mgx_handle s, int level, int which, const void* grid)
 {
     if (!s || !grid) return MGX_ERR_INVALID;
+    NO_DIST(s)
     if (!level_ok(s, level)) return s->fail(MGX_ERR_INVALID, "level out of range");
     void* dst = nullptr;
     Level* l = pick(s, level, which, &dst);
@@ -928,6 +958,7 @@ int mgx_set_level_device(mgx_handle s, int level, int which, const void* grid)
 int mgx_get_level_device(mgx_handle s, int level, int which, void* grid)
 {
     if (!s || !grid) return MGX_ERR_INVALID;
+    NO_DIST(s)
     if (!level_ok(s, level)) return s->fail(MGX_ERR_INVALID, "level out of range");
     void* src = nullptr;
     Level* l = pick(s, level, which, &src);
@@ -941,6 +972,10 @@ int mgx_zero_level(mgx_handle s, int level, int which)
 {
     if (!s) return MGX_ERR_INVALID;
     if (!level_ok(s, level)) return s->fail(MGX_ERR_INVALID, "level out of range");
+    if (s->dist) {
+        if (level != s->cfg.finest_level || which != MGX_VEC_U) return s->fail(MGX_ERR_STATE, "multi-GPU handles: only U of the finest level");
+        return dist_zero_u(s, s->dist);
+    }
     void* dst = nullptr;
     Level* l = pick(s, level, which, &dst);
     if (!dst) return s->fail(MGX_ERR_STATE, "vector not available");
@@ -975,6 +1010,7 @@ int mgx_fill_rhs(mgx_handle s, int kind, double f)
 {
     if (!s) return MGX_ERR_INVALID;
     if (kind < 0 || kind > 1) return s->fail(MGX_ERR_INVALID, "unknown rhs kind");
+    if (s->dist) return dist_fill(s, s->dist, MGX_VEC_B, kind, f, 0);
     void* grid = nullptr;
     Level* l = pick(s, s->cfg.finest_level, MGX_VEC_B, &grid);
     const dim3 blk(256), grd((l->N + 1 + 255) / 256, l->N + 1);
@@ -987,6 +1023,7 @@ int mgx_fill_rhs(mgx_handle s, int kind, double f)
 int mgx_fill_guess_random(mgx_handle s, uint64_t seed)
 {
     if (!s) return MGX_ERR_INVALID;
+    if (s->dist) return dist_fill(s, s->dist, MGX_VEC_U, 0, 0.0, seed);
     void* grid = nullptr;
     Level* l = pick(s, s->cfg.finest_level, MGX_VEC_U, &grid);
     const dim3 blk(256), grd((l->N + 1 + 255) / 256, l->N + 1);
@@ -1009,6 +1046,7 @@ int mgx_fill_guess_random(mgx_handle s, uint64_t seed)
 
 #define OP_PROLOGUE(lvl_min)                                                              \
     if (!s) return MGX_ERR_INVALID;                                                       \
+    NO_DIST(s)                                                                            \
     if (level < (lvl_min) || level > s->cfg.finest_level)                                 \
         return s->fail(MGX_ERR_INVALID, "level out of range for this operator");          \
     MIXED_GUARD(level)
@@ -1072,6 +1110,7 @@ int mgx_prolong(mgx_handle s, int level)
 int mgx_bottom_solve(mgx_handle s)
 {
     if (!s) return MGX_ERR_INVALID;
+    NO_DIST(s)
     if (s->cfg.bottom != MGX_BOTTOM_EXACT) return s->fail(MGX_ERR_STATE, "handle was created with bottom = SMOOTH");
     MIXED_GUARD(s->cfg.coarsest_level)
     bottom_solve(s);
@@ -1082,6 +1121,10 @@ int mgx_residual_norm(mgx_handle s, int level, double* out)
 {
     if (!s || !out) return MGX_ERR_INVALID;
     if (!level_ok(s, level)) return s->fail(MGX_ERR_INVALID, "level out of range");
+    if (s->dist) {
+        if (level != s->cfg.finest_level) return s->fail(MGX_ERR_STATE, "multi-GPU handles: residual norm of the finest level only");
+        return dist_norm(s, s->dist, out);
+    }
     void* gu = nullptr; void* gb = nullptr;
     Level* l = pick(s, level, MGX_VEC_U, &gu);
     (void)pick(s, level, MGX_VEC_B, &gb);
@@ -1090,6 +1133,11 @@ int mgx_residual_norm(mgx_handle s, int level, double* out)
 
 int mgx_vcycle(mgx_handle s, int level)
 {
+    if (s && s->dist) {
+        if (level != s->cfg.finest_level) return s->fail(MGX_ERR_STATE, "multi-GPU handles: V-cycles from the finest level only");
+        int rc = dist_vcycle(s, s->dist);
+        return rc ? rc : dist_sync(s, s->dist);
+    }
     OP_PROLOGUE(s->cfg.coarsest_level)
     s->zero_in_level = -1;
     vcycle(s, level);
@@ -1099,6 +1147,7 @@ int mgx_vcycle(mgx_handle s, int level)
 int mgx_vcycle_zero(mgx_handle s)
 {
     if (!s) return MGX_ERR_INVALID;
+    NO_DIST(s)
     MIXED_GUARD(s->cfg.finest_level)
     double unused = 0.0;
     int rc = cycle_body(s, false, true, &unused);
@@ -1109,6 +1158,7 @@ int mgx_vcycle_zero(mgx_handle s)
 int mgx_fmg(mgx_handle s)
 {
     if (!s) return MGX_ERR_INVALID;
+    NO_DIST(s)
     MIXED_GUARD(s->cfg.finest_level)
     int rc = fmg(s);
     if (rc) return rc;
@@ -1119,6 +1169,7 @@ int mgx_fmg(mgx_handle s)
 int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double* history, int history_cap)
 {
     if (!s || max_cycles < 0 || !(tol >= 0.0)) return MGX_ERR_INVALID;
+    if (s->dist) return dist_solve(s, s->dist, tol, max_cycles, stats, history, history_cap);
     const int L = s->cfg.finest_level;
     const bool do_fmg = (s->cfg.schedule == MGX_SCHEDULE_FMG);
     std::vector<double> hist;
@@ -1237,6 +1288,12 @@ int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double
 int mgx_profile_reset(mgx_handle s)
 {
     if (!s) return MGX_ERR_INVALID;
+    if (s->dist) {
+        int rc = dist_prof_collect(s, s->dist);
+        if (rc) return rc;
+        for (int i = 0; i < MGX_PROF_COUNT; ++i) { s->dist->prof_ms[i] = 0.0; s->dist->prof_launches[i] = 0; s->dist->prof_sweeps[i] = 0; }
+        return MGX_OK;
+    }
     int rc = prof_collect(s);
     if (rc) return rc;
     for (int i = 0; i < MGX_PROF_COUNT; ++i) { s->prof_ms[i] = 0.0; s->prof_launches[i] = 0; s->prof_sweeps[i] = 0; }
@@ -1246,6 +1303,14 @@ int mgx_profile_reset(mgx_handle s)
 int mgx_profile_get(mgx_handle s, mgx_profile* out)
 {
     if (!s || !out) return MGX_ERR_INVALID;
+    if (s->dist) {
+        int rc = dist_prof_collect(s, s->dist);
+        if (rc) return rc;
+        for (int i = 0; i < MGX_PROF_COUNT; ++i) {
+            out->ms[i] = s->dist->prof_ms[i]; out->launches[i] = s->dist->prof_launches[i]; out->sweeps[i] = s->dist->prof_sweeps[i];
+        }
+        return MGX_OK;
+    }
     int rc = prof_collect(s);
     if (rc) return rc;
     for (int i = 0; i < MGX_PROF_COUNT; ++i) {
@@ -1259,6 +1324,7 @@ int mgx_profile_get(mgx_handle s, mgx_profile* out)
 int mgx_time_smoother(mgx_handle s, int sweeps, double* ms)
 {
     if (!s || !ms || sweeps < 1) return MGX_ERR_INVALID;
+    NO_DIST(s)
     hipEvent_t a, b;
     HIPCHK(s, hipEventCreate(&a));
     HIPCHK(s, hipEventCreate(&b));
@@ -1502,5 +1568,110 @@ int mgx_slab_residual_sumsq(const mgx_slab* s, const void* u, const void* b, int
         launch_residual<float, 1>((const float*)u, (const float*)b, nullptr, 0, scratch, sum_dev, 1.0, N, pitch, row_lo, row_hi, rpc, (hipStream_t)stream, -1, s->rows);
     return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_HIP;
 }
+
+// ---- multi-GPU: ranks, plans, helpers ----------------------------------------------------------------
+int mgx_create_rank(const mgx_config* cfg, int rank, int world, const void* rccl_id, const mgx_transport* transport,
+                    mgx_handle* out)
+{
+    if (!cfg || !out) { g_create_error = "null argument"; return MGX_ERR_INVALID; }
+    *out = nullptr;
+    if (cfg->coarsest_level < 2 || cfg->finest_level < cfg->coarsest_level || cfg->finest_level > 15 ||
+        cfg->mu1 < 0 || cfg->mu2 < 0 || !(cfg->omega > 0.0 && cfg->omega < 2.0) || cfg->smoother < 0 || cfg->smoother > 1 ||
+        cfg->dtype < 0 || cfg->dtype > 2 || cfg->restrict_mode < 0 || cfg->restrict_mode > 1 || cfg->bottom < 0 || cfg->bottom > 1 ||
+        (rank >= 0 && (world < 1 || rank >= world)) || (rank < 0 && cfg->n_gpus < 2)) {
+        g_create_error = "invalid configuration";
+        return MGX_ERR_INVALID;
+    }
+    mgx_solver* s = new (std::nothrow) mgx_solver();
+    if (!s) { g_create_error = "out of host memory"; return MGX_ERR_ALLOC; }
+    s->cfg = *cfg;
+    s->cfg.schedule = MGX_SCHEDULE_V;          // multi-GPU handles run V-cycles (mgx.h)
+    const int rc = dist_create(s, &s->cfg, rank, world, rccl_id, transport);
+    if (rc != MGX_OK) { g_create_error = s->err; mgx_destroy(s); return rc; }
+    *out = s;
+    return MGX_OK;
+}
+
+int mgx_rccl_unique_id(void* out128)
+{
+    if (!out128) return MGX_ERR_INVALID;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return MGX_ERR_HIP;
+    std::memset(out128, 0, 128);
+    std::memcpy(out128, &id, sizeof(id) < 128 ? sizeof(id) : 128);
+    return MGX_OK;
+}
+
+long mgx_dist_exchanges(mgx_handle s) { return (s && s->dist) ? s->dist->exchanges : -1; }
+
+int mgx_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream)
+{
+    if (hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return MGX_ERR_HIP;
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? MGX_OK : MGX_ERR_HIP;
+}
+
+int mgx_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream)
+{
+    if (hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return MGX_ERR_HIP;
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? MGX_OK : MGX_ERR_HIP;
+}
+
+struct mgx_dist_planner { mgx::DistPlanner p; };
+
+int mgx_plan_create(const mgx_config* cfg, int n_slabs, int g, int fold, int deep, mgx_plan_handle* out)
+{
+    if (!cfg || !out) { g_plan_error = "null argument"; return MGX_ERR_INVALID; }
+    *out = nullptr;
+    const int cut = dist_cut_level(*cfg, n_slabs);
+    mgx_dist_planner* h = new (std::nothrow) mgx_dist_planner();
+    if (!h) return MGX_ERR_ALLOC;
+    if (h->p.init(plan_cfg_of(*cfg, n_slabs, g, cut, fold != 0, deep != 0)) != MGX_OK) {
+        g_plan_error = h->p.err;
+        delete h;
+        return MGX_ERR_INVALID;
+    }
+    *out = h;
+    return MGX_OK;
+}
+
+int mgx_plan_destroy(mgx_plan_handle p) { delete p; return MGX_OK; }
+const char* mgx_plan_last_error(void) { return g_plan_error.c_str(); }
+int mgx_plan_cut_level(mgx_plan_handle p) { return p ? p->p.c.cut : -1; }
+
+int mgx_plan_level(mgx_plan_handle p, int level, mgx_dist_level* out)
+{
+    if (!p || !out || level <= p->p.c.cut || level > p->p.c.finest) return MGX_ERR_INVALID;
+    *out = p->p.L(level);
+    return MGX_OK;
+}
+
+int mgx_plan_cut_share(mgx_plan_handle p, int* row0, int* rows)
+{
+    if (!p || !row0 || !rows) return MGX_ERR_INVALID;
+    *row0 = p->p.c_row0; *rows = p->p.c_rows;
+    return MGX_OK;
+}
+
+int mgx_plan_guess_set(mgx_plan_handle p, int all_rows)
+{
+    if (!p) return MGX_ERR_INVALID;
+    if (all_rows) p->p.guess_set(); else p->p.guess_changed();
+    return MGX_OK;
+}
+
+static int plan_emit(mgx_plan_handle p, mgx_dist_op* ops, int cap, bool norm)
+{
+    if (!p || (!ops && cap > 0)) return MGX_ERR_INVALID;
+    std::vector<mgx_dist_op> v;
+    // emit on a copy first: a too-small buffer must not advance the planner's halo state
+    mgx::DistPlanner trial = p->p;
+    if (norm) trial.emit_norm(v); else trial.emit_vcycle(v);
+    if ((int)v.size() > cap) return -(int)v.size();
+    p->p = trial;
+    for (size_t i = 0; i < v.size(); ++i) ops[i] = v[i];
+    return (int)v.size();
+}
+int mgx_plan_vcycle(mgx_plan_handle p, mgx_dist_op* ops, int cap) { return plan_emit(p, ops, cap, false); }
+int mgx_plan_norm(mgx_plan_handle p, mgx_dist_op* ops, int cap) { return plan_emit(p, ops, cap, true); }
 
 } // extern "C"

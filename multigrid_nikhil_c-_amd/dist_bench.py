@@ -1,5 +1,12 @@
-"""bench.py's N > 1 leg: one process per GPU (torch.distributed.run), RCCL halo
-exchange, the same 8192^2 problem split into row slabs (strong scaling)."""
+"""bench.py's N > 1 leg: one process per GPU, each rank a libmgx multi-GPU handle
+(mgx_create_rank: csrc/mgx_dist.hpp) owning one row slab of BASELINE config 4's grid; halo rows move by
+RCCL send/recv over xGMI on the slab's stream (built-in transport).  torch.distributed (gloo) is only
+the control plane here: it hands rank 0's ncclUniqueId to the other ranks, and carries the barrier and
+the max-over-ranks of the timed region the bench contract asks for.
+
+Rehearsal on a 1-GPU box (RCCL refuses two ranks on one device): MGX_DIST_SINGLE_DEVICE=1
+MGX_DIST_BACKEND=gloo puts every rank on device 0 and swaps the RCCL transport for the host-staged
+gloo one (transport.py) - same C++ executor, plans and kernels; the timing then means nothing."""
 from __future__ import annotations
 
 import json
@@ -12,55 +19,26 @@ import torch
 import torch.distributed as dist
 
 from . import binding as B
-from .dist import DistMultigrid, HipCoarseSolver, HipSlabOps
+from .transport import StagedTransport, broadcast_rccl_id
 
 HBM_PEAK_GBS = 8000.0
 
 
-def _hash_uniform(rows, cols, N, seed=12345):
-    """u0 ~ U(-1,1) from the global node index (independent of the decomposition)"""
-    idx = (rows.to(torch.int64) - 1) * (N - 1) + (cols.to(torch.int64) - 1) + seed * 1000003
-    x = idx * 6364136223846793005 + 1442695040888963407
-    x = x ^ (x >> 29)
-    x = x * (-4658895280553007687)
-    x = x ^ (x >> 32)
-    return ((x >> 11) & ((1 << 52) - 1)).to(torch.float64) / float(1 << 51) - 1.0
-
-
-def _rhs_sine(rows, cols, N):
-    h = 1.0 / N
-    x = cols.to(torch.float64) * h
-    y = rows.to(torch.float64) * h
-    return h * h * 8.0 * torch.pi ** 2 * torch.sin(2 * torch.pi * x) * torch.sin(2 * torch.pi * y)
-
-
-def default_cut(finest, coarsest, world, halo):
-    """levels up to 2048^2 are replicated: below that a replicated level costs
-    less than the exchanges a distributed one needs (DESIGN.md "Multi-GPU")"""
-    cut = max(coarsest, min(finest - 2, 11))
-    while cut < finest - 1 and ((1 << (cut + 1)) // world) < 2 * halo:
-        cut += 1
-    return cut
-
-
-def single_gpu_reference(args, L, steps):
+def single_gpu_reference(args, L, steps, device):
     """rank 0 only: the same workload on ONE GPU through the ordinary handle
     (untimed part of the job; gives the like-for-like strong-scaling baseline)"""
-    import time as _t
-
     mg = B.Multigrid(finest_level=L, coarsest_level=min(args.coarsest, L), mu0=0, mu1=args.mu1, mu2=args.mu2,
                      omega=args.omega, smoother=B.SMOOTHER_RBGS if args.smoother == "rbgs" else B.SMOOTHER_JACOBI,
-                     dtype=B.DTYPE_F32 if args.dtype == "f32" else B.DTYPE_F64, schedule=B.SCHEDULE_V,
-                     device=torch.cuda.current_device())
+                     dtype=B.DTYPE_F32 if args.dtype == "f32" else B.DTYPE_F64, schedule=B.SCHEDULE_V, device=device)
     try:
         mg.fill_rhs(1, 0.0)
         mg.fill_guess_random(12345)
         mg.solve(tol=0.0, max_cycles=1)
         mg.synchronize()
-        t0 = _t.perf_counter()
+        t0 = time.perf_counter()
         st, _ = mg.solve(tol=0.0, max_cycles=steps)
         mg.synchronize()
-        secs = _t.perf_counter() - t0
+        secs = time.perf_counter() - t0
         return {"value": st.fine_updates / secs, "unit": "updates/s", "ms_per_step": secs / steps * 1e3, "steps": steps}
     finally:
         mg.close()
@@ -70,73 +48,78 @@ def run(args, emit=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # Rehearsal mode for a 1-GPU box (RCCL refuses two ranks on one device): backend gloo with
-    # host-staged halos, every rank on device 0.  The default is what the contract asks for:
-    # one rank per GPU, backend nccl (= RCCL over xGMI).
-    backend = os.environ.get("MGX_DIST_BACKEND", "nccl")
-    if os.environ.get("MGX_DIST_SINGLE_DEVICE"):
+    backend = os.environ.get("MGX_DIST_BACKEND", "nccl")          # data plane: "nccl" = the built-in RCCL transport
+    rehearsal = bool(os.environ.get("MGX_DIST_SINGLE_DEVICE"))
+    if rehearsal:
         local = 0
-    torch.cuda.set_device(local)
-    use_pg = world > 1 or bool(os.environ.get("MGX_FORCE_DIST"))
-    if use_pg:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    dtype = torch.float32 if args.dtype == "f32" else torch.float64
     if args.dtype == "mixed":
-        raise SystemExit("--dtype mixed is a single-GPU configuration in this round")
-    per = 2 if args.smoother == "rbgs" else 1
-    halo = per * args.mu1 + max(per * args.mu2, 2)
+        raise SystemExit("--dtype mixed is a single-GPU configuration")
+    # control plane
+    dist.init_process_group("gloo")
+    assert dist.get_world_size() == world and world == args.gpus, (dist.get_world_size(), world, args.gpus)
     L = args.level
-    ref = None
-    if rank == 0 and world > 1:
-        ref = single_gpu_reference(args, L, max(1, min(args.steps, 5)))
-    torch.cuda.synchronize()
-    cut = default_cut(L, args.coarsest, world, halo)
-    cfg = dict(mu1=args.mu1, mu2=args.mu2, omega=args.omega, smoother=args.smoother,
-               restrict_mode=B.RESTRICT_CONSISTENT, bottom=B.BOTTOM_EXACT)
-    ops = HipSlabOps(dtype)
-    coarse = HipCoarseSolver(cut, min(args.coarsest, cut), cfg, dtype)
-    mg = DistMultigrid(ops, coarse, L, cut, mu1=args.mu1, mu2=args.mu2, omega=args.omega, smoother=args.smoother,
-                       restrict_mode=cfg["restrict_mode"], staged_halo=(backend != "nccl"))
-    mg.profile = True
-    mg.set_fine("b", _rhs_sine)
-    mg.set_fine("u", _hash_uniform)
     n = (1 << L) - 1
+    cfg = dict(finest_level=L, coarsest_level=min(args.coarsest, L), mu0=0, mu1=args.mu1, mu2=args.mu2, omega=args.omega,
+               smoother=B.SMOOTHER_RBGS if args.smoother == "rbgs" else B.SMOOTHER_JACOBI,
+               dtype=B.DTYPE_F32 if args.dtype == "f32" else B.DTYPE_F64, schedule=B.SCHEDULE_V, device=local, profile=1)
+    ref = None
+    if rank == 0:
+        ref = single_gpu_reference(args, L, max(1, min(args.steps, 5)), local)
+    dist.barrier()
+    transport = None
+    if backend == "nccl":
+        rccl_id = broadcast_rccl_id()
+        mg = B.Multigrid.rank(rank, world, rccl_id=rccl_id, **cfg)
+        wire = "RCCL send/recv (built-in transport, ncclCommInitRank over xGMI)"
+    else:
+        transport = StagedTransport()
+        mg = B.Multigrid.rank(rank, world, transport=transport.struct, **cfg)
+        wire = f"{backend} with host-staged halos (rehearsal transport)"
+    plan = B.Plan(world, rank, **{k: v for k, v in cfg.items() if k not in ("device", "profile")})
+    cut = plan.cut
+    halo = plan.level(L).halo
 
     def barrier():
-        torch.cuda.synchronize()
-        if use_pg:
-            dist.barrier()
-        torch.cuda.synchronize()
+        mg.synchronize()
+        dist.barrier()
 
+    mg.fill_rhs(1, 0.0)
+    mg.fill_guess_random(12345)
     # the "V-cycles to 1e-8" half of the metric (untimed)
-    k_tol, hist0 = mg.solve(tol=1e-8, max_cycles=60)
-    mg.set_fine("u", _hash_uniform)
-    for _ in range(args.warmup):
-        mg.vcycle()
-        mg.residual_norm()
-    mg.fine_updates = 0.0
-    mg.reset_profile()
+    st0, hist0 = mg.solve(tol=1e-8, max_cycles=60)
+    mg.fill_guess_random(12345)
+    if args.warmup > 0:
+        mg.solve(tol=0.0, max_cycles=args.warmup)
+    mg.profile_reset()
+    ex0 = mg.exchanges()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        mg.vcycle()
-        mg.residual_norm()
+    st, hist = mg.solve(tol=0.0, max_cycles=args.steps)       # exactly K x (one V-cycle + residual norm)
     barrier()
     secs = time.perf_counter() - t0
-    t = torch.tensor([secs], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if use_pg:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = torch.tensor([secs], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     secs = float(t.item())
-    prof = mg.collect_profile()
+    ranks_seen = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(ranks_seen)
+    prof = mg.profile()
+    exchanges = mg.exchanges() - ex0
+    assert st.cycles == args.steps
     if rank == 0:
+        if int(ranks_seen.item()) != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the collective saw {int(ranks_seen.item())} ranks")
         es = 4 if args.dtype == "f32" else 8
-        achieved = prof["bytes"] / (prof["ms"] * 1e-3) / 1e9 if prof["ms"] > 0 else 0.0
+        # rank 0's finest-level smoother passes: each launch must move its slab rows once
+        # (read v, read b, write v'), halo rows recomputed by the deep-halo scheme included
+        g = plan.level(L)
+        rows = g.rows
+        sm_ms, sm_launches, sm_sweeps = prof["ms"][0], max(prof["launches"][0], 1), prof["sweeps"][0]
+        avg_ms = sm_ms / sm_launches
+        bytes_per_launch = 3.0 * es * rows * n
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
             "metric": "fine_grid_stencil_updates_per_sec",
-            "value": mg.fine_updates / secs,
+            "value": st.fine_updates / secs,
             "unit": "updates/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -148,38 +131,37 @@ def run(args, emit=None):
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"2D Poisson {1 << L}^2 (n={n} interior), {L - min(args.coarsest, cut) + 1}-level V({args.mu1},{args.mu2}) cycle, "
+                "workload": f"2D Poisson {1 << L}^2 (n={n} interior), {L - cfg['coarsest_level'] + 1}-level V({args.mu1},{args.mu2}) cycle, "
                             f"{'weighted Jacobi w=%.4f' % args.omega if args.smoother == 'jacobi' else 'red-black Gauss-Seidel'}, "
-                            f"{args.dtype}, row slabs over {world} GPUs on levels {cut + 1}..{L} ({mg.halo}-row deep halos on the finest level, "
-                            f"{'RCCL send/recv' if backend == 'nccl' else backend + ' with host-staged halos (rehearsal)'}, "
-                            f"{'transfers folded into the smoother passes' if mg.fold else 'separate transfer kernels'}), "
-                            f"levels <= {cut} replicated, exact bottom solve at {(1 << min(args.coarsest, cut)) - 1}^2",
-                "finest_level": L, "coarsest_level": min(args.coarsest, cut), "cut_level": cut, "mu1": args.mu1,
-                "mu2": args.mu2, "smoother": args.smoother, "step": "one V-cycle + residual norm",
-                "parallelism": f"slab{world}",
+                            f"{args.dtype}, row slabs over {world} GPUs on levels {cut + 1}..{L} ({halo}-row deep halos on the finest "
+                            f"level, {wire}, transfers folded into the smoother passes), levels <= {cut} replicated, exact "
+                            f"bottom solve at {(1 << cfg['coarsest_level']) - 1}^2",
+                "finest_level": L, "coarsest_level": cfg["coarsest_level"], "cut_level": cut, "mu1": args.mu1,
+                "mu2": args.mu2, "smoother": args.smoother, "step": "one V-cycle + residual norm (mgx_solve loop body)",
+                "parallelism": f"slab{world}", "driver": "C++ (mgx_create_rank), one process per GPU",
+                "rehearsal_all_ranks_on_one_device": rehearsal,
             },
-            "vcycles_to_1e-8": k_tol if hist0[-1] <= 1e-8 * hist0[0] else None,
+            "ranks_seen_by_collective": int(ranks_seen.item()),
+            "vcycles_to_1e-8": st0.cycles if st0.converged else None,
             "single_gpu_same_workload": ref,
-            "speedup_vs_single_gpu_same_workload": (mg.fine_updates / secs / ref["value"]) if ref else None,
-            "halo_exchanges_per_step": mg.exchanges_timed / max(args.steps, 1),
+            "speedup_vs_single_gpu_same_workload": (st.fine_updates / secs / ref["value"]) if ref else None,
+            "halo_exchanges_per_step": exchanges / max(args.steps, 1),
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("k_jacobi_fused / k_jacobi_cycle<%s,K,PRE,POST,%d> on the slab's row window (deep halos, "
-                           "transfers folded into the passes)" if mg.fold else
-                           "k_jacobi_fused<%s,K,%d> (slab rows, deep halos; separate transfer kernels)")
-                          % ("double" if es == 8 else "float", 1 if args.smoother == "rbgs" else 0),
+                "kernel": "k_jacobi_fused / k_jacobi_cycle<%s,K,PRE,POST,%d> on rank 0's slab of the finest level (deep halos, "
+                          "transfers folded into the passes)" % ("double" if es == 8 else "float", 1 if args.smoother == "rbgs" else 0),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "how": "rank 0: torch.cuda events (current stream = the kernels' stream) around every finest-level "
-                       "smoothing block in the timed steps; bytes = 3*sizeof(T) per point actually updated, halo rows "
-                       "recomputed by the deep-halo scheme included",
-                "launches_timed": prof["launches"],
+                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms, "launches_timed": sm_launches,
+                "sweeps_per_pass": sm_sweeps / sm_launches,
+                "how": "rank 0: HIP events on the slab's stream around every finest-level smoothing block in the timed steps; "
+                       "bytes = 3*sizeof(T) x (slab rows incl. halos) x n per pass, charged once per pass",
             },
         }
         if emit is not None:
             emit(out)
         else:
             print(json.dumps(out), flush=True)
-    if use_pg:
-        dist.barrier()
-        dist.destroy_process_group()
+    mg.close()
+    dist.barrier()
+    dist.destroy_process_group()

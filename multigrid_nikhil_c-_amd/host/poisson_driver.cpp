@@ -4,9 +4,12 @@
 // names, on libmgx.  Adds what SURVEY D10 notes the reference never prints:
 // the residual norms and timing.
 //
-//   poisson_driver [finest=10] [coarsest=7] [mu0=30] [mu1=10] [mu2=10] [f32|f64]
+//   poisson_driver [finest=10] [coarsest=7] [mu0=30] [mu1=10] [mu2=10] [f32|f64] [n_gpus=1]
 //
-// Defaults are the reference's compile-time globals (PS:17-22, 123, 127).
+// Defaults are the reference's compile-time globals (PS:17-22, 123, 127).  n_gpus > 1 splits the
+// finest levels into row slabs, one per GPU (mgx_config.n_gpus; MGX_DRIVER_DEVICES="0,0,1,1" places
+// the slabs explicitly - several may share a device); the solve is then V-cycles from the zero guess
+// (PS:630, 575-627): the FMG pass of PS:727 is a single-GPU schedule in this library.
 #include "mgx_reference_api.hpp"
 
 #include <chrono>
@@ -24,6 +27,20 @@ template <typename Real> static int run(const parameters& prm)
     std::vector<matrix_elements_for_jacobi>& jacobi_matrices = build_hierarchy<Real>(prm);
 
     std::vector<Real> f_global = globalforcefunction<Real>();                 // PS:725
+    if (prm.n_gpus > 1) {
+        mgx_stats st{};
+        std::vector<double> hist;
+        std::vector<Real> solution_finest = multigrid_solver(f_global, 1e-8, 60, &st, &hist);
+        std::cout << "Size of finest level solution is " << solution_finest.size() << "\n";   // PS:728
+        const std::size_t n = std::size_t(mgx_level_n(prm.finest_level));
+        std::printf("solve to 1e-8: %d V-cycles on %d GPUs (row slabs), %.3f ms, ||r||/||r0|| = %.3e, %.3e fine-grid updates/s, "
+                    "u(1/2,1/2) = %.7f\n", st.cycles, prm.n_gpus, st.seconds * 1e3, st.final_residual / st.initial_residual,
+                    st.seconds > 0 ? st.fine_updates / st.seconds : 0.0, double(solution_finest[(n / 2) * n + n / 2]));
+        for (std::size_t k = 0; k < hist.size(); ++k) std::printf("  cycle %2zu  ||r||_2 = %.6e\n", k, hist[k]);
+        std::cout << "Program Running Correctly ";                            // PS:729
+        std::cout << std::endl;
+        return 0;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<Real> solution_finest =
         fullmultigrid(q, jacobi_matrices[jacobi_matrices.size() - 1], f_global);   // PS:727
@@ -60,6 +77,14 @@ int main(int argc, char** argv)
     if (argc > 4) prm.mu1 = std::atoi(argv[4]);
     if (argc > 5) prm.mu2 = std::atoi(argv[5]);
     const bool f32 = (argc > 6 && std::strcmp(argv[6], "f32") == 0);
+    if (argc > 7) prm.n_gpus = std::atoi(argv[7]);
+    if (const char* dv = std::getenv("MGX_DRIVER_DEVICES")) {
+        int i = 0;
+        for (const char* p = dv; *p && i < MGX_MAX_GPUS; ++i) {
+            prm.devices[i] = int(std::strtol(p, const_cast<char**>(&p), 10));
+            if (*p == ',') ++p;
+        }
+    }
     try {
         return f32 ? run<float>(prm) : run<double>(prm);
     } catch (const std::exception& e) {

@@ -1,8 +1,10 @@
-"""The multi-GPU driver's logic on CPU: world_size-2 (and 4) gloo process
-groups, numpy slab operators standing in for the device, checked against the
-oracle's single-process V-cycle.  Covers the halo exchange, the deep-halo
-shrinking sweeps, slab restriction/prolongation offsets, the all_gather at the
-cut-over level and the all_reduce of the norm."""
+"""The multi-GPU driver's logic on CPU.  The slab plans libmgx emits (mgx_plan_*: the host logic of
+csrc/mgx_dist_plan.hpp, the same planner the GPU executor runs) are executed here by world_size-2,
+-4 and -8 gloo process groups over numpy slab operators (tests/plan_exec.py), and checked against the
+oracle's single-process V-cycle.  Covers the halo exchange, the deep-halo shrinking passes, the slab
+restriction / prolongation offsets, the all-gather at the cut level and the all-reduce of the norm.
+The numpy operators poison with NaN every row a call does not promise to leave valid, so a plan that
+relied on a stale halo row fails."""
 import os
 import sys
 
@@ -16,36 +18,37 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _mgx_cfg(cfg):
+    return dict(finest_level=cfg["finest"], coarsest_level=cfg["coarsest"], cut_level=cfg["cut"], mu1=cfg["mu1"], mu2=cfg["mu2"],
+                omega=cfg["omega"], smoother=1 if cfg["smoother"] == "rbgs" else 0, restrict_mode=cfg["restrict_mode"],
+                bottom=cfg["bottom"], schedule=0)
+
+
 def _worker(rank, world, port, cfg, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge
     from dist_cpu_ops import CpuSlabOps, OracleCoarseSolver
     from oracle import pyoracle as po
+    from plan_exec import PlanRunner
 
     pkg = ge.load_package()
-    from multigrid_nikhil_c_amd.dist import DistMultigrid
-
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        mcfg = _mgx_cfg(cfg)
+        plan = pkg.Plan(world, rank, fold=cfg.get("fold", True), deep=cfg.get("deep", True), **mcfg)
+        assert plan.cut == cfg["cut"]
         ops = CpuSlabOps(torch.float64)
         coarse = OracleCoarseSolver(po, cfg["cut"], cfg["coarsest"], cfg)
-        mg = DistMultigrid(ops, coarse, cfg["finest"], cfg["cut"], mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"],
-                           smoother=cfg["smoother"], restrict_mode=cfg["restrict_mode"], fold=cfg.get("fold", True),
-                           deep=cfg.get("deep", True))
+        mg = PlanRunner(pkg, ops, coarse, plan, mcfg)
         L = cfg["finest"]
         n = (1 << L) - 1
-        b = po.rhs_sine(L)
-        u0 = po.fill_uniform((n, n), 12345)
-        bt, ut = torch.from_numpy(np.pad(b, 1)), torch.from_numpy(np.pad(u0, 1))
-        mg.set_fine("b", lambda r, c, N: bt[r, c])
-        mg.set_fine("u", lambda r, c, N: ut[r, c])
+        mg.set_fine("b", np.pad(po.rhs_sine(L), 1))
+        mg.set_fine("u", np.pad(po.fill_uniform((n, n), 12345), 1))
         k, hist = mg.solve(tol=1e-8, max_cycles=cfg["max_cycles"])
-        own = mg.own_interior("u").numpy().copy()
-        lv = mg.lv[L]
         if rank == 0:
             ret["hist"] = hist
-        ret[f"rows{rank}"] = (max(lv.own_lo, 1), min(lv.own_hi, lv.N), own)
+        ret[f"rows{rank}"] = mg.own_interior()
         ret[f"exch{rank}"] = mg.exchanges
     finally:
         dist.destroy_process_group()
@@ -76,9 +79,9 @@ BASE = dict(finest=8, cut=6, coarsest=4, mu1=2, mu2=1, omega=2.0 / 3.0, smoother
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("smoother,mu1,mu2", [("jacobi", 2, 1), ("jacobi", 3, 3), ("rbgs", 1, 1), ("jacobi", 2, 0),
                                               ("jacobi", 0, 2)])
-def test_slab_vcycle_matches_single_process_oracle(po, world, smoother, mu1, mu2, fold):
-    """fold = True: transfers folded into the smoother passes (ops.cycle, the default);
-    False: separate restriction / prolongation / norm operators"""
+def test_slab_plans_match_the_single_process_oracle(po, world, smoother, mu1, mu2, fold):
+    """fold = True: transfers folded into the smoother passes (CYCLE operations, the default);
+    False: separate SMOOTH / RESTRICT / PROLONG / SUMSQ operations"""
     cfg = dict(BASE, smoother=smoother, mu1=mu1, mu2=mu2, fold=fold)
     got = _run(world, cfg)
     u_ref, h_ref = _reference(po, cfg)
@@ -113,7 +116,7 @@ def test_three_distributed_levels_and_replicated_coarse(po, deep):
 
 def test_eight_ranks_three_distributed_levels(po):
     """the round-end layout in miniature: 8 ranks, three slab levels above a replicated cut
-    level (bench.py --gpus 8 at 16384^2 distributes levels 14..12 and replicates <= 11)"""
+    level (bench.py --gpus 8 at 16384^2 distributes levels 14..11 and replicates <= 10)"""
     cfg = dict(BASE, finest=10, cut=7, coarsest=5, mu1=2, mu2=2, max_cycles=3)
     got = _run(8, cfg)
     u_ref, h_ref = _reference(po, cfg)
@@ -127,3 +130,31 @@ def test_eight_ranks_three_distributed_levels(po):
         assert np.max(np.abs(own - u_ref[lo - 1:hi - 1])) <= 1e-12 * np.max(np.abs(u_ref))
     assert rows == (1 << 10) - 1                       # the slabs tile the unknown rows exactly
     assert got["exch0"] <= (len(h) - 1) * (1 + 2) + 2, got["exch0"]
+
+
+def test_plan_geometry_and_defaults(pkg):
+    """the planner alone (no process group): the bench's own 8-GPU layout at 16384^2"""
+    cfgs = dict(finest_level=14, coarsest_level=7, mu1=10, mu2=10)
+    plans = [pkg.Plan(8, g, **cfgs) for g in range(8)]
+    assert all(p.cut == 10 for p in plans)             # 2048^2 and up distributed, <= 1024^2 replicated
+    for l in range(11, 15):
+        N = 1 << l
+        geo = [p.level(l) for p in plans]
+        assert geo[0].own_lo == 0 and geo[-1].own_hi == N + 1
+        for a, b in zip(geo, geo[1:]):
+            assert a.own_hi == b.own_lo                # the slabs tile rows 0..N
+        for g in geo:
+            assert g.row0 == max(g.own_lo - g.halo, 0) and g.rows == min(g.own_hi + g.halo, N + 1) - g.row0
+            assert N // 8 >= g.halo
+    # every slab emits the same sequence of operation codes (the one-process executor relies on it)
+    for p in plans:
+        p.guess_set(True)
+    for _ in range(2):
+        seqs = [[(o.op, o.level, o.depth) for o in p.vcycle()] for p in plans]
+        assert all(s == seqs[0] for s in seqs)
+        ex = [o for o in seqs[0] if o[0] == pkg.binding.DOP_EXCHANGE]
+        assert len(ex) <= 4                            # one per distributed level
+        assert all([o.op for o in p.norm()] == [pkg.binding.DOP_ALLREDUCE_NORM] for p in plans)
+    # slabs too thin for their halos are refused with a message, not mis-planned
+    with pytest.raises(pkg.MgxError, match="raise cut_level"):
+        pkg.Plan(8, 0, finest_level=9, coarsest_level=5, cut_level=6, mu1=10, mu2=10)

@@ -1,123 +1,178 @@
-"""The multi-GPU driver over the real HIP slab operators on one MI355X:
-world_size 1 (no communication) must reproduce mgx_solve bit for bit, and two
-ranks sharing the GPU (gloo with host-staged halos, because RCCL refuses two
-ranks on one device) must reproduce it too."""
+"""The C++ multi-GPU driver (csrc/mgx_dist.hpp) on one MI355X, through the C-ABI:
+  * mgx_create(cfg.n_gpus = P) with every slab on device 0 must reproduce the single-GPU mgx_solve
+    bit for bit at P = 2, 4, 8 (same kernels on row ranges, halos carrying the neighbour's values);
+  * mgx_create_rank: one process per rank, two and four ranks sharing the GPU over the host-staged
+    gloo transport (RCCL refuses two ranks on one device), same bits again;
+  * the built-in RCCL transport at world 1 (communicator, all-gather, all-reduce really run);
+  * the PS-shaped C++ driver binary with an n_gpus argument."""
 import os
 import sys
 
 import numpy as np
 import pytest
-import torch  # noqa: F401  (before libmgx.so is loaded: see HipSlabOps.__init__ on the two HIP runtimes)
+import torch  # noqa: F401  (before libmgx.so is loaded: the two HIP runtimes)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _setup(pkg, po, cfg, staged=False, fold=None):
-    import torch
+def _cfg(pkg, c):
+    return dict(finest_level=c["finest"], coarsest_level=c["coarsest"], mu1=c["mu1"], mu2=c["mu2"], omega=2.0 / 3.0,
+                smoother=1 if c["smoother"] == "rbgs" else 0, schedule=0, dtype=0 if c.get("dtype") == "f32" else 1)
 
-    from multigrid_nikhil_c_amd.dist import DistMultigrid, HipCoarseSolver, HipSlabOps
 
-    dt = torch.float32 if cfg.get("dtype") == "f32" else torch.float64
-    ccfg = dict(mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"], smoother=cfg["smoother"], restrict_mode=0, bottom=0)
-    mg = DistMultigrid(HipSlabOps(dt), HipCoarseSolver(cfg["cut"], cfg["coarsest"], ccfg, dt), cfg["finest"], cfg["cut"],
-                       mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"], smoother=cfg["smoother"], staged_halo=staged,
-                       fold=cfg.get("fold", fold), deep=cfg.get("deep"))
-    L = cfg["finest"]
+def _problem(po, c):
+    L = c["finest"]
     n = (1 << L) - 1
-    npdt = np.float32 if dt == torch.float32 else np.float64
-    b = po.rhs_sine(L).astype(npdt)
-    u0 = po.fill_uniform((n, n), 12345).astype(npdt)
-    bt, ut = torch.from_numpy(np.pad(b, 1)).cuda(), torch.from_numpy(np.pad(u0, 1)).cuda()
-    mg.set_fine("b", lambda r, c, N: bt[r, c])
-    mg.set_fine("u", lambda r, c, N: ut[r, c])
-    return mg, b, u0
+    dt = np.float32 if c.get("dtype") == "f32" else np.float64
+    return po.rhs_sine(L).astype(dt), po.fill_uniform((n, n), 12345).astype(dt)
 
 
-def _single(pkg, cfg, b, u0, cycles):
-    with pkg.Multigrid(finest_level=cfg["finest"], coarsest_level=cfg["coarsest"], mu1=cfg["mu1"], mu2=cfg["mu2"],
-                       omega=cfg["omega"], smoother=1 if cfg["smoother"] == "rbgs" else 0, schedule=0,
-                       dtype=0 if cfg.get("dtype") == "f32" else 1) as mg:
+def _single(pkg, c, b, u0, cycles):
+    with pkg.Multigrid(**_cfg(pkg, c)) as mg:
         mg.set_rhs(b)
         mg.set_guess(u0)
         st, h = mg.solve(tol=0.0, max_cycles=cycles)
         return h, mg.get_solution()
 
 
-@pytest.mark.parametrize("fold", [True, False])
-@pytest.mark.parametrize("smoother,mu1,mu2", [("jacobi", 2, 1), ("jacobi", 10, 10), ("rbgs", 2, 1), ("jacobi", 3, 0),
-                                              ("jacobi", 0, 2), ("rbgs", 1, 3)])
-def test_world1_slab_driver_equals_single_gpu_solve(pkg, po, smoother, mu1, mu2, fold):
-    """fold: the transfers ride on the smoother passes (mgx_slab_cycle, the default) or run as
-    separate slab kernels; either way the same bits as mgx_solve"""
-    cfg = dict(finest=10, cut=8, coarsest=6, mu1=mu1, mu2=mu2, omega=2.0 / 3.0, smoother=smoother, fold=fold)
-    mg, b, u0 = _setup(pkg, po, cfg)
-    hist = [mg.residual_norm()]
-    for _ in range(3):
-        mg.vcycle()
-        hist.append(mg.residual_norm())
-    h_ref, u_ref = _single(pkg, cfg, b, u0, 3)
-    assert np.array_equal(mg.own_interior("u").cpu().numpy(), u_ref)       # same kernels, same order: bitwise
-    assert np.allclose(hist, h_ref, rtol=1e-13, atol=0)
-    _, h_orc = po.Solver(finest_level=10, coarsest_level=6, mu1=mu1, mu2=mu2, smoother=1 if smoother == "rbgs" else 0,
-                         schedule=0).solve(b, u0, tol=0.0, max_cycles=3)
-    assert np.all(np.abs(np.array(hist) - h_orc) <= 1e-10 * h_orc + 1e-13 * h_orc[0])
+CASES = [
+    # P, smoother, mu1, mu2, fold, deep, dtype, finest, cut
+    (2, "jacobi", 2, 1, True, True, "f64", 10, 8),
+    (2, "jacobi", 10, 10, True, True, "f64", 10, 7),
+    (2, "rbgs", 2, 1, True, True, "f64", 10, 8),
+    (2, "jacobi", 3, 0, True, True, "f64", 10, 8),
+    (2, "jacobi", 0, 2, True, True, "f64", 10, 8),
+    (2, "rbgs", 1, 3, True, True, "f64", 10, 8),
+    (2, "jacobi", 3, 2, False, True, "f64", 9, 7),
+    (2, "jacobi", 3, 2, True, False, "f64", 9, 7),          # the correction is exchanged
+    (2, "jacobi", 7, 6, True, True, "f64", 10, 7),          # several passes per block, folded first / last
+    (2, "rbgs", 3, 3, True, True, "f64", 10, 7),
+    (2, "jacobi", 8, 9, True, True, "f64", 10, 7),
+    (2, "rbgs", 4, 5, True, True, "f64", 10, 7),
+    (4, "jacobi", 10, 10, True, True, "f64", 10, 7),        # interior slabs have two edges
+    (4, "rbgs", 2, 1, True, True, "f64", 10, 7),
+    (8, "jacobi", 2, 2, True, True, "f64", 10, 7),
+    (8, "jacobi", 10, 10, True, True, "f64", 11, 8),
+    (2, "jacobi", 10, 10, True, True, "f32", 10, 7),
+    (2, "rbgs", 2, 2, True, True, "f32", 10, 7),
+    (4, "jacobi", 4, 3, False, True, "f32", 10, 7),
+]
 
 
-def _worker(rank, world, port, cfg, ret):
+@pytest.mark.parametrize("P,smoother,mu1,mu2,fold,deep,dtype,finest,cut", CASES)
+def test_n_gpus_on_one_device_equal_the_single_gpu_solve(pkg, po, monkeypatch, P, smoother, mu1, mu2, fold, deep, dtype, finest, cut):
+    c = dict(finest=finest, coarsest=5, mu1=mu1, mu2=mu2, smoother=smoother, dtype=dtype)
+    monkeypatch.setenv("MGX_DIST_FOLD", "1" if fold else "0")
+    monkeypatch.setenv("MGX_DIST_DEEP", "1" if deep else "0")
+    b, u0 = _problem(po, c)
+    h_ref, u_ref = _single(pkg, c, b, u0, 3)
+    with pkg.Multigrid(n_gpus=P, devices=[0] * P, cut_level=cut, **_cfg(pkg, c)) as mg:
+        mg.set_rhs(b)
+        mg.set_guess(u0)
+        st, h = mg.solve(tol=0.0, max_cycles=3)
+        u = mg.get_solution()
+        ex = mg.exchanges()
+        assert mg.residual_norm() == pytest.approx(h[-1], rel=1e-13)
+    assert st.cycles == 3 and st.fine_updates == 3 * (mu1 + mu2) * float((1 << finest) - 1) ** 2
+    assert np.array_equal(u, u_ref)                               # same kernels, same order: bitwise
+    assert np.allclose(h, h_ref, rtol=1e-13, atol=0)
+    if deep and fold and mu1 > 0 and mu2 > 0:
+        # communication-avoiding plan: one exchange per distributed level per cycle (+ the first norm)
+        assert ex <= 3 * (finest - cut) + 1, ex
+    if dtype == "f64":
+        _, h_orc = po.Solver(finest_level=finest, coarsest_level=5, mu1=mu1, mu2=mu2, smoother=1 if smoother == "rbgs" else 0,
+                             schedule=0).solve(b, u0, tol=0.0, max_cycles=3)
+        assert np.all(np.abs(np.array(h) - h_orc) <= 1e-10 * h_orc + 1e-13 * h_orc[0])
+
+
+def test_multi_gpu_handle_device_fills_and_unsupported_calls(pkg):
+    """inputs generated on the device (what bench.py does) equal the single-GPU fills; operator
+    entry points that make no sense on a slab handle say so"""
+    kw = dict(finest_level=10, coarsest_level=6, mu1=3, mu2=3, schedule=0)
+    with pkg.Multigrid(**kw) as one, pkg.Multigrid(n_gpus=4, devices=[0] * 4, cut_level=8, **kw) as many:
+        for mg in (one, many):
+            mg.fill_rhs(1, 0.0)
+            mg.fill_guess_random(777)
+        assert np.array_equal(many.get_level(10, pkg.VEC_B), one.get_level(10, pkg.VEC_B))
+        assert np.array_equal(many.get_solution(), one.get_solution())
+        s1, h1 = one.solve(tol=1e-8, max_cycles=30)
+        s4, h4 = many.solve(tol=1e-8, max_cycles=30)
+        assert s1.cycles == s4.cycles and s4.converged == 1
+        assert np.array_equal(many.get_solution(), one.get_solution())
+        with pytest.raises(pkg.MgxError, match="multi-GPU"):
+            many.smooth(10, 1)
+        with pytest.raises(pkg.MgxError, match="multi-GPU"):
+            many.get_level(9, pkg.VEC_U)
+        many.zero_level(10, pkg.VEC_U)
+        assert not many.get_solution().any()
+    with pytest.raises(pkg.MgxError):
+        pkg.Multigrid(n_gpus=2, devices=[0, 0], dtype=pkg.DTYPE_MIXED, **kw)
+    with pytest.raises(pkg.MgxError, match="raise cut_level"):
+        pkg.Multigrid(n_gpus=8, devices=[0] * 8, cut_level=6, finest_level=9, coarsest_level=5, mu1=10, mu2=10, schedule=0)
+
+
+def test_rank_handle_with_the_builtin_rccl_transport_at_world_one(pkg, po):
+    """ncclCommInitRank, ncclAllGather and ncclAllReduce really run (one rank: RCCL refuses two on one
+    device); same bits as the single-GPU solve"""
+    c = dict(finest=10, coarsest=6, mu1=4, mu2=3, smoother="jacobi")
+    b, u0 = _problem(po, c)
+    h_ref, u_ref = _single(pkg, c, b, u0, 3)
+    with pkg.Multigrid.rank(0, 1, rccl_id=pkg.rccl_unique_id(), cut_level=8, **_cfg(pkg, c)) as mg:
+        mg.set_rhs(b)
+        mg.set_guess(u0)
+        st, h = mg.solve(tol=0.0, max_cycles=3)
+        assert np.array_equal(mg.get_solution(), u_ref)
+        assert np.allclose(h, h_ref, rtol=1e-13, atol=0)
+
+
+def _worker(rank, world, port, c, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT)
-    import torch
     import torch.distributed as dist
 
     import __graft_entry__ as ge
     from oracle import pyoracle as po
 
     pkg = ge.load_package()
-    torch.cuda.set_device(0)
+    from multigrid_nikhil_c_amd.transport import StagedTransport
+
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        mg, b, u0 = _setup(pkg, po, cfg, staged=True)
-        hist = [mg.residual_norm()]
-        for _ in range(cfg["cycles"]):
-            mg.vcycle()
-            hist.append(mg.residual_norm())
-        lv = mg.lv[cfg["finest"]]
-        ret[f"rows{rank}"] = (max(lv.own_lo, 1), min(lv.own_hi, lv.N), mg.own_interior("u").cpu().numpy())
-        if rank == 0:
-            ret["hist"] = hist
+        tr = StagedTransport()
+        b, u0 = _problem(po, c)
+        with pkg.Multigrid.rank(rank, world, transport=tr.struct, cut_level=c["cut"], device=0, **_cfg(pkg, c)) as mg:
+            mg.set_rhs(b)
+            mg.set_guess(u0)
+            st, h = mg.solve(tol=0.0, max_cycles=c["cycles"])
+            u = np.zeros_like(b)
+            mg.get_solution_into(u)
+            N = 1 << c["finest"]
+            lo, hi = max(rank * (N // world), 1), min((rank + 1) * (N // world) + (1 if rank == world - 1 else 0), N)
+            ret[f"rows{rank}"] = (lo, hi, u[lo - 1:hi - 1].copy())
+            ret[f"calls{rank}"] = dict(tr.calls)
+            if rank == 0:
+                ret["hist"] = h
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,smoother,mu1,mu2,fold", [
-    (2, "jacobi", 3, 2, True), (2, "rbgs", 1, 1, True), (2, "jacobi", 10, 10, True), (2, "jacobi", 3, 2, False),
-    # several passes per block with the transfers folded into the first / last one
-    (2, "jacobi", 7, 6, True), (2, "rbgs", 3, 3, True), (2, "jacobi", 10, 10, False), (2, "jacobi", 8, 9, True),
-    (2, "jacobi", 6, 7, True), (2, "rbgs", 4, 5, True),
-    # interior ranks have two slab edges
-    (4, "jacobi", 10, 10, True), (4, "rbgs", 2, 1, True),
-    # float slabs (world < 0 marks them)
-    (-2, "jacobi", 10, 10, True), (-2, "rbgs", 2, 2, True), (-2, "jacobi", 4, 3, False)])
-def test_ranks_sharing_one_gpu_equal_single_gpu_solve(pkg, po, world, smoother, mu1, mu2, fold):
+@pytest.mark.parametrize("world,smoother,mu1,mu2,dtype", [(2, "jacobi", 10, 10, "f64"), (2, "rbgs", 2, 1, "f64"),
+                                                          (4, "jacobi", 3, 2, "f64"), (2, "jacobi", 4, 3, "f32")])
+def test_rank_processes_sharing_one_gpu_equal_the_single_gpu_solve(pkg, po, world, smoother, mu1, mu2, dtype):
     import torch.multiprocessing as mp
 
-    dtype = "f32" if world < 0 else "f64"
-    world = abs(world)
-    big = mu1 >= 7 or world > 2
-    cfg = dict(finest=10 if big else 9, cut=7, coarsest=5, mu1=mu1, mu2=mu2, omega=2.0 / 3.0, smoother=smoother,
-               cycles=3, fold=fold, dtype=dtype, deep=not (mu1 == 3 and mu2 == 2))   # (3,2): the correction is exchanged
+    c = dict(finest=10, cut=7, coarsest=5, mu1=mu1, mu2=mu2, smoother=smoother, dtype=dtype, cycles=3)
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, 29700 + os.getpid() % 1000, cfg, ret), nprocs=world, join=True)
-    n = (1 << cfg["finest"]) - 1
-    npdt = np.float32 if dtype == "f32" else np.float64
-    b, u0 = po.rhs_sine(cfg["finest"]).astype(npdt), po.fill_uniform((n, n), 12345).astype(npdt)
-    h_ref, u_ref = _single(pkg, cfg, b, u0, 3)
+    mp.spawn(_worker, args=(world, 29700 + os.getpid() % 1000, c, ret), nprocs=world, join=True)
+    b, u0 = _problem(po, c)
+    h_ref, u_ref = _single(pkg, c, b, u0, 3)
     assert np.allclose(ret["hist"], h_ref, rtol=1e-13, atol=0)
     for r in range(world):
         lo, hi, own = ret[f"rows{r}"]
         assert np.array_equal(own, u_ref[lo - 1:hi - 1])
+        assert ret[f"calls{r}"]["allgather"] == 3 and ret[f"calls{r}"]["allreduce"] == 4
 
 
 def test_poisson_driver_binary_runs_the_reference_sequence(pkg):
@@ -135,23 +190,31 @@ def test_poisson_driver_binary_runs_the_reference_sequence(pkg):
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("solve to 1e-8")][0]
     assert "u(1/2,1/2) = 0.29468" in out.stdout
     assert int(line.split()[3]) <= 16
+    # the same program on several GPUs: `... f64 <n_gpus>`; here every slab on device 0
+    env = dict(os.environ, MGX_DRIVER_DEVICES="0,0,0,0")
+    out4 = subprocess.run([exe, "11", "7", "0", "2", "1", "f64", "4"], capture_output=True, text=True, timeout=300, env=env)
+    assert out4.returncode == 0, out4.stderr
+    assert "Size of finest level solution is 4190209" in out4.stdout       # 2047^2
+    assert "Program Running Correctly" in out4.stdout and "4 GPUs" in out4.stdout
+    assert "u(1/2,1/2) = 0.29468" in out4.stdout
 
 
-def test_config4_grid_slab_driver_equals_single_gpu_solve(pkg, po):
-    """BASELINE config 4's grid (16384^2, levels 14..7) through the slab driver exactly as
-    bench.py --gpus N sets it up (levels 14..12 on slabs, <= 11 in the replicated handle),
-    world 1 on this one GPU: the reference's V(10,10) cycle must reproduce mgx_solve bit for bit"""
-    import gc
-
-    cfg = dict(finest=14, cut=11, coarsest=7, mu1=10, mu2=10, omega=2.0 / 3.0, smoother="jacobi")
-    mg, b, u0 = _setup(pkg, po, cfg)
-    hist = [mg.residual_norm()]
-    mg.vcycle()
-    hist.append(mg.residual_norm())
-    own = mg.own_interior("u").cpu().numpy()
-    del mg
-    gc.collect()
-    h_ref, u_ref = _single(pkg, cfg, b, u0, 1)
-    assert np.array_equal(own, u_ref)
-    assert np.allclose(hist, h_ref, rtol=1e-13, atol=0)
-    assert hist[1] < 0.1 * hist[0]
+def test_config4_grid_on_eight_slabs_equals_the_single_gpu_solve(pkg):
+    """BASELINE config 4's grid (16384^2, levels 14..7, the reference's V(10,10)) through the C++
+    driver with the decomposition `bench.py --gpus 8` uses (levels 14..11 on slabs, <= 10 replicated),
+    all eight slabs on this one GPU: one cycle, bit for bit the single-GPU mgx_solve"""
+    kw = dict(finest_level=14, coarsest_level=7, mu1=10, mu2=10, schedule=0)
+    with pkg.Multigrid(**kw) as one:
+        one.fill_rhs(1, 0.0)
+        one.fill_guess_random(12345)
+        s1, h1 = one.solve(tol=0.0, max_cycles=1)
+        u1 = one.get_solution()
+    with pkg.Multigrid(n_gpus=8, devices=[0] * 8, **kw) as many:
+        many.fill_rhs(1, 0.0)
+        many.fill_guess_random(12345)
+        s8, h8 = many.solve(tol=0.0, max_cycles=1)
+        assert many.exchanges() <= 4 + 1
+        u8 = many.get_solution()
+    assert np.array_equal(u8, u1)
+    assert np.allclose(h8, h1, rtol=1e-13, atol=0)
+    assert h8[1] < 0.1 * h8[0]
