@@ -276,7 +276,7 @@ inline int fold_kcap(const FuseCfg& f, int smoother, int N, int post, bool f64)
 inline double fold_pass_cost(int K, int smoother, int N, int post, bool f64)
 {
     const bool rbgs = (smoother == MGX_SMOOTHER_RBGS);
-    if (!cycle_k_supported(K, rbgs, f64)) return -1.0;
+    if (!cycle_k_supported(K, rbgs, f64, post)) return -1.0;
     if (rbgs) return K <= 4 ? 1.0 : (K == 6 ? 1.1 : (K == 8 ? 1.3 : 2.4));
     if (K <= 5) return 1.0;
     if (!f64) return K == 6 ? 1.34 : 1.53;
@@ -326,7 +326,8 @@ int fold_plan(const mgx_solver* s, const Level& l, int mu, bool pre, int post, i
             sum += forced[i];
             const int K = per * forced[i];
             const bool folded = (i == 0 && pre) || (i == nf - 1 && post != 0);
-            ok = ok && K <= 10 && (folded ? cycle_k_supported(K, rbgs, l.f64) : (K != 7 && K != 9 && (!rbgs || K % 2 == 0)));
+            const int q = (i == nf - 1) ? post : 0;
+            ok = ok && K <= 10 && (folded ? cycle_k_supported(K, rbgs, l.f64, q, pre && i == 0) : (K != 7 && K != 9 && (!rbgs || K % 2 == 0)));
         }
         if (ok && sum == mu) {
             for (int i = 0; i < nf; ++i) parts[i] = forced[i];
@@ -407,7 +408,7 @@ bool fold_eligible(const mgx_solver* s, const Level& l, int mu, bool pre = false
     int parts[64];
     const int np = fold_plan(s, l, mu, pre, post, parts);
     for (int p = 0; p < np; ++p)
-        if (!cycle_k_supported(per * parts[p], rbgs, l.f64)) return false;
+        if (!cycle_k_supported(per * parts[p], rbgs, l.f64, p == np - 1 ? post : 0, pre && p == 0)) return false;
     // the norm partials of the folded pass must fit the reduction buffer
     return true;
 }
@@ -1414,8 +1415,11 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
     const int N = 1 << f->level;
     const long pitch = level_pitch(f->level, f->dtype);
     const int first = 1 - f->row0, last = N - f->row0;        // local unknown rows [first, last)
-    const FuseCfg fc = fuse_cfg();
+    FuseCfg fc = fuse_cfg();
     const int post = coarse_b ? 1 : (sum_dev ? 2 : 0);
+    if (coarse_e && coarse_b) {                  // correction and restriction may meet in one pass: at most 8 levels
+        fc.fold_kmax = std::min(fc.fold_kmax, 8); fc.fold_kmax_big = std::min(fc.fold_kmax_big, 8);
+    }
     int parts[64];
     const int np = plan_folded(fc, rbgs ? MGX_SMOOTHER_RBGS : MGX_SMOOTHER_JACOBI, N, mu, post, sizeof(T) == 8, parts);
     const T om = (T)omega;
@@ -1455,7 +1459,7 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
         if (hi > lo) {
             const int R = fuse_rows(fc, N, K, sizeof(T) == 8);
             if (P || Q) {
-                if (!cycle_k_supported(K, rbgs, sizeof(T) == 8)) return MGX_ERR_INVALID;
+                if (!cycle_k_supported(K, rbgs, sizeof(T) == 8, Q, P)) return MGX_ERR_INVALID;
                 fa.row_lo = lo + f->row0; fa.row_hi = hi + f->row0;
                 int rc;
                 if (P && Q == 2) rc = launch_cycle<T, 1, 2, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, R, st);

@@ -35,8 +35,18 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace mgx {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;                 // 4 waves
@@ -831,9 +841,11 @@ template <int K, int POST, int W> constexpr int cycle_out_lanes() { return kWave
 // (plain scalars, assigned member by member: aggregate copies of a 24-byte
 // Trip<double> were lowered to scratch memcpys)
 template <typename T, int CW> struct CycleState {
-    // POST 1: left / centre / right residuals of rows 2I-1 (t*) and 2I (m*) of the
-    // coarse row being assembled, per coarse column of the lane
-    T tl[CW], tc[CW], tr[CW], ml[CW], mc[CW], mr[CW];
+    // POST 1: what is left of rows 2I-1 (top) and 2I (mid) of the coarse row being assembled, per
+    // coarse column of the lane, as the partial sums of PS:539-542 in its order:
+    //   ct = nw + ne, tc = n (top row);  em = ((w + e) + n), mc = c (mid row)
+    // four values instead of the six residuals: the folded restriction is register-bound
+    T ct[CW], tc[CW], em[CW], mc[CW];
     double acc;                 // POST 2: sum of r^2
 };
 
@@ -897,9 +909,54 @@ cycle_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
     }
 }
 
-template <typename T, int K, int PRE, int POST, int SM, bool EDGE, int P>
+// ---- the rhs window of a deep folded pass in LDS -------------------------------------------------
+// A pass of K levels uses every rhs row at K (+1 with a residual stage) consecutive steps: a delay
+// line of K + 1 vectors per lane.  In registers that is 4 (K + 1) VGPRs; with the level windows
+// (12 (K + 1)), the prefetch slots and the transfer state the 10-level folded passes needed more than
+// 256 and ran at one wave per SIMD with accumulator-register spills.  For deep passes the delay line
+// therefore lives in LDS: each wave owns a ring of kBRing rows of 1 KiB (64 lanes x 16 B), row y at
+// slot y mod kBRing; the step loop is unrolled kBRing-fold so that every slot is a compile-time
+// ds_read_b128 / ds_write_b128 offset from ONE per-lane address (no address arithmetic, no register
+// moves); no barrier (a wave only ever touches its own ring).  LDS instructions do not occupy the
+// vector ALU, which is what these passes are bound by.  Same values, same order: same bits.
+constexpr int kBRing = 12;                     // >= K + 1 for K <= 10, multiple of the 3 rotation phases
+template <typename T, int K, int POST, int SM> constexpr bool cycle_b_in_lds() { return sizeof(T) == 8 && K >= 8; }
+template <typename T> struct LdsVec;
+template <> struct LdsVec<double> { typedef double v __attribute__((ext_vector_type(2))); };
+template <> struct LdsVec<float> { typedef float v __attribute__((ext_vector_type(4))); };
+template <typename T> using lds_vec_ptr = __attribute__((address_space(3))) typename LdsVec<T>::v*;
+__device__ __forceinline__ void ring_put(lds_vec_ptr<double> r, int slot, const double2& v)
+{
+    LdsVec<double>::v t = {v.x, v.y};
+    r[slot * kWave] = t;
+}
+__device__ __forceinline__ double2 ring_get(lds_vec_ptr<double> r, int slot)
+{
+    const LdsVec<double>::v t = r[slot * kWave];
+    return make_double2(t.x, t.y);
+}
+__device__ __forceinline__ void ring_put(lds_vec_ptr<float> r, int slot, const float4& v)
+{
+    LdsVec<float>::v t = {v.x, v.y, v.z, v.w};
+    r[slot * kWave] = t;
+}
+__device__ __forceinline__ float4 ring_get(lds_vec_ptr<float> r, int slot)
+{
+    const LdsVec<float>::v t = r[slot * kWave];
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+constexpr int ring_slot(int m) { return ((m % kBRing) + kBRing) % kBRing; }
+// rows a folded pass loads ahead of itself (one register slot pair per row in flight).  Three
+// everywhere, except the deep pre-smoothing passes with the restriction stage: they are the most
+// register-hungry kernels of the library, a step of theirs is ~800 vector instructions long, and two
+// rows in flight keep them at two waves per SIMD without spills.
+template <bool BL, int POST> constexpr int cycle_pfd() { return (BL && POST == 1) ? 2 : kPrefetch; }
+
+// RP: phase of the step inside the kBRing-fold unrolled loop (BL) or inside the 3-fold one (!BL);
+// the window-rotation phase is RP % 3 either way
+template <typename T, int K, int PRE, int POST, int SM, bool EDGE, int RP, bool BL>
 __device__ __forceinline__ void
-cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&bw)[K + 1],
+cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&bw)[BL ? 1 : K + 1], lds_vec_ptr<T> ring,
            typename VecOf<T>::type (&nin)[kPfStages], typename VecOf<T>::type (&nbn)[kPfStages], PreFetch<T, VecOf<T>::W / 2>& pe,
            CycleState<T, VecOf<T>::W / 2>& cs, int y,
            const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
@@ -909,6 +966,7 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
     constexpr int CW = W / 2;
+    constexpr int P = RP % 3;
     constexpr int S_OLD = (P + 1) % 3, S_MID = (P + 2) % 3, S_NEW = P;
     constexpr int bnd_lo = 0;
     const int bnd_hi = N;
@@ -921,7 +979,7 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     const V bn = nbn[0];
 #pragma unroll
     for (int q = 0; q + 1 < kPfStages; ++q) { nin[q] = nin[q + 1]; nbn[q] = nbn[q + 1]; }
-    cycle_loads<T, EDGE>(nin[kPfStages - 1], nbn[kPfStages - 1], y + kPrefetch, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win);
+    cycle_loads<T, EDGE>(nin[kPfStages - 1], nbn[kPfStages - 1], y + cycle_pfd<BL, POST>(), pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win);
     if (PRE) {
         // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624).  The coarse
         // values of row y were fetched during the previous step (pe.a = coarse row y>>1,
@@ -950,17 +1008,34 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     // Jacobi passes without a residual stage keep c1 * b in the window (see jacobi_vec_pre);
     // the residual of POST needs b itself
     constexpr bool PREMUL = (SM == 0 && POST == 0);
+    V b0;                                             // rhs row y-1 (times c1 when PREMUL): bw[0]
+    if constexpr (PREMUL) b0 = vscale(c1, bn);
+    else b0 = bn;
+    if constexpr (BL) {
+        // the compiler must not carry ring contents in registers from step to step (it would,
+        // every offset being a constant): make the address opaque once per step
+        asm volatile("" : "+v"(ring));
+        ring_put(ring, ring_slot(RP), b0);
+    } else {
 #pragma unroll
-    for (int j = K; j > 0; --j) bw[j] = bw[j - 1];
-    if constexpr (PREMUL) bw[0] = vscale(c1, bn);
-    else bw[0] = bn;
+        for (int j = K; j > 0; --j) bw[j] = bw[j - 1];
+        bw[0] = b0;
+    }
+    // bw[j] = rhs row y-1-j
+    auto bwin = [&](auto jc) -> V {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j == 0) return b0;
+        else if constexpr (BL) return ring_get(ring, ring_slot(RP - j));
+        else return bw[j];
+    };
     lev[0][S_NEW] = in;
-#pragma unroll
-    for (int j = 1; j <= K; ++j) {
+    static_for<1, K + 1>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
         const int row = y - j;
+        const V cb = bwin(std::integral_constant<int, j - 1>{});
         V o;
-        if constexpr (PREMUL) o = jacobi_vec_pre(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1);
-        else o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1,
+        if constexpr (PREMUL) o = jacobi_vec_pre(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], cb, c0, c1);
+        else o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], cb, c0, c1,
                                  row + (int)(col & 1));
         if (EDGE) {
             mask_cols(o, col, N);
@@ -968,11 +1043,11 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
         }
         if (j == K) vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);
         if (j < K || POST) lev[j][S_NEW] = o;
-    }
+    });
     if (POST) {
         // residual of the new iterate on row rho = y-K-1 (rows rho-1, rho, rho+1 of level K)
         const int rho = y - K - 1;
-        V res = residual_vec(lev[K][S_OLD], lev[K][S_MID], lev[K][S_NEW], bw[K]);
+        V res = residual_vec(lev[K][S_OLD], lev[K][S_MID], lev[K][S_NEW], bwin(std::integral_constant<int, K>{}));
         if (EDGE) {
             mask_cols(res, col, N);
             if (!(rho > bnd_lo && rho < bnd_hi)) res = Z;
@@ -999,8 +1074,8 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
 #pragma unroll
             for (int k = 0; k < CW; ++k) {
                 // PS:539-542 order: ((nw+ne)+sw)+se + 2*(((w+e)+n)+s) + 4*c
-                T corners = cs.tl[k] + cs.tr[k]; corners = corners + cl[k]; corners = corners + cr[k];
-                T edges = cs.ml[k] + cs.mr[k]; edges = edges + cs.tc[k]; edges = edges + cc[k];
+                T corners = cs.ct[k] + cl[k]; corners = corners + cr[k];
+                const T edges = cs.em[k] + cc[k];
                 o[k] = wgt * ((corners + (T)2 * edges) + (T)4 * cs.mc[k]);
                 if (EDGE && (ccol + k == 0 || ccol + k >= ca.NC)) o[k] = (T)0;
             }
@@ -1016,8 +1091,12 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
             }
 #pragma unroll
             for (int k = 0; k < CW; ++k) {
-                cs.tl[k] = odd ? cl[k] : cs.tl[k]; cs.tc[k] = odd ? cc[k] : cs.tc[k]; cs.tr[k] = odd ? cr[k] : cs.tr[k];
-                cs.ml[k] = odd ? cs.ml[k] : cl[k]; cs.mc[k] = odd ? cs.mc[k] : cc[k]; cs.mr[k] = odd ? cs.mr[k] : cr[k];
+                const T lr = cl[k] + cr[k];                    // nw + ne of the next coarse row / w + e of this one
+                const T em = lr + cs.tc[k];                    // (w + e) + n   (uses the OLD top centre)
+                cs.em[k] = odd ? cs.em[k] : em;
+                cs.mc[k] = odd ? cs.mc[k] : cc[k];
+                cs.ct[k] = odd ? lr : cs.ct[k];
+                cs.tc[k] = odd ? cc[k] : cs.tc[k];
             }
         }
     }
@@ -1028,8 +1107,9 @@ __device__ __forceinline__ double
 cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
            const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
            long pitch, long cpitch, long col, int N, int r0, int r1, bool ld, bool st, T c0, T c1, bool zero_in,
-           const CycleWin& win)
+           const CycleWin& win, lds_vec_ptr<T> ring)
 {
+    constexpr bool BL = cycle_b_in_lds<T, K, POST, SM>();
     using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
     constexpr int CW = W / 2;
@@ -1039,39 +1119,60 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     const long ccol = col / 2;
     const bool cld = ld && (ccol + CW < cpitch);
     V lev[K + 1][3];      // level windows in rotating slots; level K only when POST
-    V bw[K + 1];          // bw[j] = rhs row y-1-j
+    V bw[BL ? 1 : K + 1]; // bw[j] = rhs row y-1-j (in the wave's LDS ring instead when BL)
 #pragma unroll
-    for (int j = 0; j <= K; ++j) { lev[j][0] = Z; lev[j][1] = Z; lev[j][2] = Z; bw[j] = Z; }
+    for (int j = 0; j <= K; ++j) { lev[j][0] = Z; lev[j][1] = Z; lev[j][2] = Z; }
+#pragma unroll
+    for (int j = 0; j < (BL ? 1 : K + 1); ++j) bw[j] = Z;
+    if constexpr (BL) {
+#pragma unroll
+        for (int q = 0; q < kBRing; ++q) ring_put(ring, q, Z);
+    }
     CycleState<T, CW> cs;
     cs.acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < CW; ++k) {
-        cs.tl[k] = cs.tc[k] = cs.tr[k] = (T)0;
-        cs.ml[k] = cs.mc[k] = cs.mr[k] = (T)0;
-    }
+    for (int k = 0; k < CW; ++k) cs.ct[k] = cs.tc[k] = cs.em[k] = cs.mc[k] = (T)0;
     CycleArgs ca;
     ca.cpitch = cpitch; ca.NC = N / 2; ca.r0 = r0; ca.r1 = r1; ca.zero_in = zero_in; ca.win = win;
     const int y0 = r0 - K - ETOP;
     ca.y_end = r1 + K + EBOT;                       // exclusive end of the steps that matter
     const int steps = (ca.y_end - y0 + 2) / 3 * 3;  // rounded up to whole rotations
-    V nin[3][kPfStages], nbn[3][kPfStages];        // [rotation phase][queue position]
+    constexpr int PFD = cycle_pfd<BL, POST>();
+    V nin[PFD][kPfStages], nbn[PFD][kPfStages];    // [step phase mod PFD][queue position]
 #pragma unroll
-    for (int q = 0; q < kPrefetch; ++q)
-        cycle_loads<T, EDGE>(nin[q % 3][q / 3], nbn[q % 3][q / 3], y0 + q, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win);
+    for (int q = 0; q < PFD; ++q)
+        cycle_loads<T, EDGE>(nin[q][0], nbn[q][0], y0 + q, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win);
     PreFetch<T, CW> pe;
 #pragma unroll
     for (int k = 0; k <= CW; ++k) { pe.a[k] = (T)0; pe.b[k] = (T)0; }
     if (PRE) coarse_loads<T, EDGE>(pe, y0, coarse_e, cpitch, ccol, N, cld, ca.win);
-    for (int y = y0; y < y0 + steps; y += 3) {
-        cycle_step<T, K, PRE, POST, SM, EDGE, 0>(lev, bw, nin[0], nbn[0], pe, cs, y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
-        cycle_step<T, K, PRE, POST, SM, EDGE, 1>(lev, bw, nin[1], nbn[1], pe, cs, y + 1, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
-        cycle_step<T, K, PRE, POST, SM, EDGE, 2>(lev, bw, nin[2], nbn[2], pe, cs, y + 2, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1);
+#define MGX_CSTEP(RP, Y) cycle_step<T, K, PRE, POST, SM, EDGE, RP, BL>(lev, bw, ring, nin[(RP) % PFD], nbn[(RP) % PFD], pe, cs, Y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1)
+    if constexpr (BL) {
+        // kBRing steps per trip so that every ring slot is a compile-time offset; the trip is left
+        // after any whole rotation (the step count stays a multiple of 3, not of kBRing)
+        const int yend = y0 + steps;
+        for (int y = y0; y < yend; y += kBRing) {
+            MGX_CSTEP(0, y); MGX_CSTEP(1, y + 1); MGX_CSTEP(2, y + 2);
+            if (y + 3 >= yend) break;
+            MGX_CSTEP(3, y + 3); MGX_CSTEP(4, y + 4); MGX_CSTEP(5, y + 5);
+            if (y + 6 >= yend) break;
+            MGX_CSTEP(6, y + 6); MGX_CSTEP(7, y + 7); MGX_CSTEP(8, y + 8);
+            if (y + 9 >= yend) break;
+            MGX_CSTEP(9, y + 9); MGX_CSTEP(10, y + 10); MGX_CSTEP(11, y + 11);
+        }
+    } else {
+        for (int y = y0; y < y0 + steps; y += 3) {
+            MGX_CSTEP(0, y); MGX_CSTEP(1, y + 1); MGX_CSTEP(2, y + 2);
+        }
     }
+#undef MGX_CSTEP
     return cs.acc;
 }
 
+// deep passes (rhs ring in LDS): ask for two workgroups per CU = two waves per SIMD, i.e. at most 256
+// registers - without it the compiler settles for one wave per SIMD and accumulator-register spills
 template <typename T, int K, int PRE, int POST, int SM = 0>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, (cycle_b_in_lds<T, K, POST, SM>() ? 2 : 1))
 k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
                const T* __restrict__ coarse_e,                       // PRE
                T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,   // POST == 1
@@ -1086,10 +1187,15 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     constexpr int ETOP = POST ? 1 : 0;
     constexpr int EBOT = POST == 1 ? 2 : (POST == 2 ? 1 : 0);
     __shared__ double wsum[kWavesPerBlock];
+    // the waves' rhs rings (deep passes only: cycle_b_in_lds)
+    constexpr bool BL = cycle_b_in_lds<T, K, POST, SM>();
+    __shared__ typename LdsVec<T>::v bring[BL ? kWavesPerBlock * kBRing * kWave : 1];
     const Tile t = wave_tile(strips, chunks);
     double acc = 0.0;
     if (t.active) {
         const int lane = threadIdx.x & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        lds_vec_ptr<T> ring = (lds_vec_ptr<T>)&bring[BL ? (wv * kBRing * kWave + lane) : 0];
         const int vx0 = t.strip * OUT - HL;
         const int vx = vx0 + lane;
         const long col = (long)vx * W;
@@ -1106,10 +1212,10 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         if (PRE) interior = interior && (y_first >> 1) >= win.crow_first && ((y_lastp >> 1) + 1) <= win.crow_last;
         if (interior)
             acc = cycle_body<T, K, PRE, POST, SM, false>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
-                                                         pitch, cpitch, col, N, r0, r1, true, st, c0, c1, zero_in != 0, win);
+                                                         pitch, cpitch, col, N, r0, r1, true, st, c0, c1, zero_in != 0, win, ring);
         else
             acc = cycle_body<T, K, PRE, POST, SM, true>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
-                                                        pitch, cpitch, col, N, r0, r1, ld, st, c0, c1, zero_in != 0, win);
+                                                        pitch, cpitch, col, N, r0, r1, ld, st, c0, c1, zero_in != 0, win, ring);
     }
     if (POST == 2) {
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);

@@ -313,8 +313,10 @@ int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, i
         default: break;
     }
     // 10 levels with folded stages: double only (the float variants, whose packed arithmetic
-    // needs aligned register pairs, exceed 256 VGPRs)
-    if constexpr (sizeof(T) == 8) {
+    // needs aligned register pairs, exceed 256 VGPRs), and not the two most register-hungry
+    // combinations (correction AND restriction in one pass; red-black GS with the restriction):
+    // with the rhs window in LDS every instantiated variant fits 256 registers = two waves per SIMD
+    if constexpr (sizeof(T) == 8 && !(PRE == 1 && POST == 1) && !(SM == 1 && POST == 1)) {
         if (K == 10) return launch_cycle_k<T, 10, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
     }
     if constexpr (SM == 0) {
@@ -329,9 +331,9 @@ int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, i
 }
 
 // levels per pass the folded kernels are instantiated for
-inline bool cycle_k_supported(int K, bool rbgs, bool f64)
+inline bool cycle_k_supported(int K, bool rbgs, bool f64, int post = 0, bool pre = false)
 {
-    if (K == 10) return f64;
+    if (K == 10) return f64 && !(pre && post == 1) && !(rbgs && post == 1);
     return rbgs ? (K == 2 || K == 4 || K == 6 || K == 8) : (K >= 1 && K <= 8 && K != 7);
 }
 

@@ -399,3 +399,30 @@ def test_full_size_cycles_against_the_oracle(pkg, po, name, cfg, cycles):
     u_ref, h_ref = po.Solver(**cfg).solve(b, u0, tol=0.0, max_cycles=cycles)
     assert hist_close(h, h_ref), (h, h_ref)
     assert np.max(np.abs(u - u_ref)) <= 1e-12 * np.max(np.abs(u_ref))
+
+
+@pytest.mark.parametrize("smoother", [0, 1])
+@pytest.mark.parametrize("plan", [("10", "10"), ("8,2", "2,8"), ("2,8", "8,2"), ("10", "5,5"), ("5,5", "10")])
+def test_deep_folded_passes_with_the_rhs_window_in_lds_are_bit_identical(pkg, po, monkeypatch, plan, smoother):
+    """the 8- and 10-level folded passes keep their rhs delay line in an LDS ring (12-fold unrolled
+    step loop, two rows in flight for the restriction variant): every explicit plan that uses them
+    must give the bits of the default plan, and the oracle's history"""
+    mu = 10 if smoother == 0 else 5            # red-black GS: levels = 2 x sweeps
+    pre, post = plan
+    if smoother == 1:
+        pre, post = [",".join(str(max(1, int(k) // 2)) for k in p.split(",")) for p in (pre, post)]
+    cfg = dict(finest_level=11, coarsest_level=8, mu1=mu, mu2=mu, schedule=0, smoother=smoother)
+    b = po.rhs_sine(11)
+    u0 = po.fill_uniform(b.shape, 4242)
+    monkeypatch.setenv("MGX_TILE_MAX_N", "0")
+    for k in ("MGX_PLAN_MIN_N", "MGX_PLAN_PRE", "MGX_PLAN_POST"):
+        monkeypatch.delenv(k, raising=False)
+    _, h0, u_ref = run_gpu(pkg, cfg, b, u0, tol=0.0, max_cycles=2)
+    monkeypatch.setenv("MGX_PLAN_MIN_N", "256")
+    monkeypatch.setenv("MGX_PLAN_PRE", pre)
+    monkeypatch.setenv("MGX_PLAN_POST", post)
+    _, h, u = run_gpu(pkg, cfg, b, u0, tol=0.0, max_cycles=2)
+    assert np.array_equal(u, u_ref), plan
+    assert np.allclose(h, h0, rtol=1e-13, atol=0)
+    _, h_orc = po.Solver(**cfg).solve(b, u0, tol=0.0, max_cycles=2)
+    assert hist_close(h, h_orc)
