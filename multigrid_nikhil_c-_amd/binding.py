@@ -17,7 +17,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmgx.so")
+# MGX_LIBMGX_PATH: another build of the same library (A/B measurements inside one GPU call)
+LIB_PATH = os.environ.get("MGX_LIBMGX_PATH") or os.path.join(_HERE, "libmgx.so")
 
 SMOOTHER_JACOBI, SMOOTHER_RBGS = 0, 1
 DTYPE_F32, DTYPE_F64, DTYPE_MIXED = 0, 1, 2

@@ -255,16 +255,14 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
 }
 
 // ---- planning the passes of a folded smoothing block ------------------------------------------
-// A folded pass of up to 5 levels is HBM-bound and costs about the same whatever its depth
-// (370-420 us at 8192^2 in double); deeper ones are VALU-bound.  Costs relative to a 5-level
-// pass, from bench.py runs with explicit plans (MGX_PLAN_PRE / MGX_PLAN_POST) and depth caps, in
-// one process each: double 6 levels 1.15, 8 levels 1.63, 10 levels 2.3 (1.8 for the passes
-// without a residual stage from 4096^2 up, which keep c1*b in their window); float 6: 1.34,
-// 8: 1.53; red-black Gauss-Seidel (levels = 2 x sweeps) 6: 1.1, 8: 1.3.  Minimising the sum
-// reproduces every measured optimum: V(6,6) and V(8,8) one pass per block (2.17 -> 1.50 and
-// 2.29 -> 1.96 ms per cycle against [3,3] / [4,4]), V(10,10) [5,5] (against [10] +4 %, [8,2] +2 %),
-// V(12,12) [6,6] (2.69 against 3.31 ms as [5,5,2]), V(9,9) [5,4], RB-GS V(4,4) one pass (1.74
-// against 2.31 ms).  kcap: MGX_FOLD_KMAX / _BIG / _NOPOST / _GS still cap the depth.
+// Pass costs relative to a pass of up to 5 levels (HBM-bound: ~385 us at 8192^2 in double whatever
+// its depth), from bench.py runs with explicit plans (MGX_PLAN_PRE / MGX_PLAN_POST) against each other
+// inside one GPU call.  Round 2, double, after the deep passes got their rhs window in LDS and
+// branch-free interior bodies (rows really in flight): 6 levels 1.05, 8 levels 1.12, 10 levels 1.46
+// (0.56 ms) - a 10-level pass now costs less than two 5-level ones, so V(10,10) is planned as ONE
+// pass per block ([10]: 1.93 ms per cycle against 2.35 as [5,5], 2.28 as [8,2], 2.35 as [6,4]).
+// float (no LDS variants, packed arithmetic): 6: 1.34, 8: 1.53; red-black Gauss-Seidel (levels =
+// 2 x sweeps) 6: 1.1, 8: 1.3, 10: 2.4.  kcap: MGX_FOLD_KMAX / _BIG / _NOPOST / _GS still cap the depth.
 inline int fold_kcap(const FuseCfg& f, int smoother, int N, int post, bool f64)
 {
     int k = N >= 8192 ? f.fold_kmax_big : f.fold_kmax;
@@ -277,12 +275,13 @@ inline double fold_pass_cost(int K, int smoother, int N, int post, bool f64)
 {
     const bool rbgs = (smoother == MGX_SMOOTHER_RBGS);
     if (!cycle_k_supported(K, rbgs, f64, post)) return -1.0;
+    (void)N;
     if (rbgs) return K <= 4 ? 1.0 : (K == 6 ? 1.1 : (K == 8 ? 1.3 : 2.4));
     if (K <= 5) return 1.0;
     if (!f64) return K == 6 ? 1.34 : 1.53;
-    if (K == 6) return 1.15;
-    if (K == 8) return 1.63;
-    return (post == 0 && N >= 4096) ? 1.8 : 2.3;
+    if (K == 6) return 1.05;
+    if (K == 8) return 1.12;
+    return 1.46;
 }
 
 // parts[] = sweeps per pass, deepest first (the last pass carries the residual stage, which is

@@ -100,6 +100,46 @@ __device__ __forceinline__ double from_right(double x)
     return __hiloint2double(dpp_shl1(__double2hiint(x)), dpp_shl1(__double2loint(x)));
 }
 
+// ---- branch-free stores for the interior bodies --------------------------------------------------
+// A conditional store (halo lanes do not store; rows outside the chunk do not either) compiles to an
+// exec-mask branch, a conditional load to a uniform branch, and every branch ends a basic block: the
+// compiler's s_waitcnt insertion then assumes the worst at each join and put `vmcnt(3)` - "all but
+// the loads issued in this very step" - in front of every row step: ONE row in flight however many
+// the code prefetched (rocprofv3: waves parked on s_waitcnt 40-65 % of their time).  The interior
+// bodies therefore contain no branch at all: stores go through a raw buffer descriptor and a lane
+// or row that must not store gets an offset beyond the descriptor's range (the hardware drops it),
+// conditional accumulations are selects, and "the input is all zero" is a template parameter.
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef int v2i32 __attribute__((ext_vector_type(2)));
+constexpr unsigned kOobOffset = 0xFFFFFF00u;       // beyond every descriptor here (arrays < 4 GiB - 256 B)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void bstore(const double2& v, __amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, v), r, voff, 0, 0);
+}
+__device__ __forceinline__ void bstore(const float4& v, __amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, v), r, voff, 0, 0);
+}
+__device__ __forceinline__ void bstore8(double v, __amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i32, v), r, voff, 0, 0);
+}
+__device__ __forceinline__ void bstore8(float2 v, __amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i32, v), r, voff, 0, 0);
+}
+// what an interior body needs to store without branches (built once per wave from uniform values)
+struct FastOut {
+    __amdgpu_buffer_rsrc_t out, cb, cz;    // fine output; coarse rhs and coarse guess (POST 1; cz empty when not wanted)
+    unsigned lane_off;                     // byte offset of this lane's vector in a fine row
+    unsigned clane_off;                    // byte offset of this lane's first coarse column in a coarse row
+    unsigned pitch_bytes, cpitch_bytes;
+};
+
 // ---- wave -> (row chunk, column strip) --------------------------------------
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an XCD and its
 // L2).  The remap gives each XCD a contiguous range of tiles, x fastest, so the
@@ -432,13 +472,20 @@ level_op(int j, const typename VecOf<T>::type& up, const typename VecOf<T>::type
 // just died, so (oldest, middle, newest) = slots ((P+1)%3, (P+2)%3, P) and no
 // window is ever shifted by register moves (the loop below runs P = 0,1,2).
 // loads of one step: input row y and rhs row y-1
-template <typename T, int K, bool EDGE>
+template <typename T, int K, bool EDGE, bool ZIN = false>
 __device__ __forceinline__ void
 fused_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
             const T* __restrict__ pv, const T* __restrict__ pb, long pitch, int r0, int r1, bool ld,
             int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, bool zero_in)
 {
     using V = typename VecOf<T>::type;
+    if constexpr (!EDGE) {
+        // interior body: no predicate, no branch (see "branch-free stores" above)
+        if constexpr (ZIN) in = vzero((V*)nullptr);
+        else in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
+        bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
+        return;
+    }
     if (EDGE) {
         // [rd_lo, rd_hi]: rows inside the allocation and not beyond a boundary row;
         // zero_in: the input is known to be all zero (PS:613 coarse guess): do not read it
@@ -447,22 +494,19 @@ fused_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
         bn = vload<V>(pb + (long)(y - 1) * pitch,
                       ld && (y - 1) > bnd_lo && (y - 1) < bnd_hi && (y - 1) >= rd_lo && (y - 1) <= rd_hi &&
                       y >= r0 - K + 2 && y < r1 + K);
-    } else {
-        in = vzero((V*)nullptr);
-        if (!zero_in) in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
-        bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
     }
 }
 
 constexpr int kPfStages = 1;                 // prefetch slots per rotation phase (2 = six rows ahead: measured slower)
 constexpr int kPrefetch = 3 * kPfStages;     // rows a marching wave loads ahead
 
-template <typename T, int K, int SM, bool EDGE, int P>
+template <typename T, int K, int SM, bool EDGE, int P, bool ZIN>
 __device__ __forceinline__ void
 fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K],
            typename VecOf<T>::type (&nin)[kPfStages], typename VecOf<T>::type (&nbn)[kPfStages], int y,
            const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po, long pitch, long col, int N,
-           int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int par_c, bool zero_in)
+           int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int par_c, bool zero_in,
+           const FastOut& fo)
 {
     using V = typename VecOf<T>::type;
     constexpr int S_OLD = (P + 1) % 3, S_MID = (P + 2) % 3, S_NEW = P;
@@ -475,7 +519,7 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
     const V in = nin[0], bn = nbn[0];
 #pragma unroll
     for (int q = 0; q + 1 < kPfStages; ++q) { nin[q] = nin[q + 1]; nbn[q] = nbn[q + 1]; }
-    fused_loads<T, K, EDGE>(nin[kPfStages - 1], nbn[kPfStages - 1], y + kPrefetch, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
+    fused_loads<T, K, EDGE, ZIN>(nin[kPfStages - 1], nbn[kPfStages - 1], y + kPrefetch, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
 #pragma unroll
     for (int j = K - 1; j > 0; --j) bw[j] = bw[j - 1];
     if constexpr (SM == 0) bw[0] = vscale(c1, bn);       // Jacobi: the window holds c1 * b (see jacobi_vec_pre)
@@ -492,15 +536,22 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
             mask_cols(o, col, N);
             if (!(row > bnd_lo && row < bnd_hi)) o = Z;          // Dirichlet rows stay zero
         }
-        if (j < K) lev[j][S_NEW] = o;
-        else vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);
+        if (j < K) {
+            lev[j][S_NEW] = o;
+        } else if constexpr (!EDGE) {
+            const unsigned at = (unsigned)row * fo.pitch_bytes + fo.lane_off;
+            bstore(o, fo.out, (st && row >= r0 && row < r1) ? at : kOobOffset);
+        } else {
+            vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);
+        }
     }
 }
 
-template <typename T, int K, int SM, bool EDGE>
+template <typename T, int K, int SM, bool EDGE, bool ZIN = false>
 __device__ __forceinline__ void
 fused_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po, long pitch, long col, int N,
-           int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int row_parity, bool zero_in)
+           int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int row_parity, bool zero_in,
+           const FastOut& fo)
 {
     using V = typename VecOf<T>::type;
     const V Z = vzero((V*)nullptr);
@@ -518,11 +569,11 @@ fused_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     V nin[3][kPfStages], nbn[3][kPfStages];        // [rotation phase][queue position]
 #pragma unroll
     for (int q = 0; q < kPrefetch; ++q)
-        fused_loads<T, K, EDGE>(nin[q % 3][q / 3], nbn[q % 3][q / 3], y0 + q, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
+        fused_loads<T, K, EDGE, ZIN>(nin[q % 3][q / 3], nbn[q % 3][q / 3], y0 + q, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
     for (int y = y0; y < y0 + steps; y += 3) {
-        fused_step<T, K, SM, EDGE, 0>(lev, bw, nin[0], nbn[0], y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
-        fused_step<T, K, SM, EDGE, 1>(lev, bw, nin[1], nbn[1], y + 1, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
-        fused_step<T, K, SM, EDGE, 2>(lev, bw, nin[2], nbn[2], y + 2, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in);
+        fused_step<T, K, SM, EDGE, 0, ZIN>(lev, bw, nin[0], nbn[0], y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in, fo);
+        fused_step<T, K, SM, EDGE, 1, ZIN>(lev, bw, nin[1], nbn[1], y + 1, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in, fo);
+        fused_step<T, K, SM, EDGE, 2, ZIN>(lev, bw, nin[2], nbn[2], y + 2, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in, fo);
     }
 }
 
@@ -557,8 +608,21 @@ k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     const bool interior = (vx0 >= 1) && ((long)(vx0 + kWave) * W < N) &&
                           (r0 - K - 1 > bnd_lo) && (r0 - K - 1 >= 0) &&
                           (r1 + K + 2 + kPrefetch < bnd_hi) && (r1 + K + 2 + kPrefetch <= rows_alloc - 1);
-    if (interior) fused_body<T, K, SM, false>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, zero_in != 0);
-    else fused_body<T, K, SM, true>(pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, zero_in != 0);
+    // the interior bodies store through 32-bit buffer offsets (local rows of this array)
+    const unsigned long out_bytes = (unsigned long)rows_alloc * (unsigned long)pitch * sizeof(T);
+    FastOut fo;
+    fo.out = make_rsrc(vout, out_bytes < 0xFFFFF000ul ? (unsigned)out_bytes : 0u);
+    fo.cb = fo.out; fo.cz = fo.out;                  // unused here
+    fo.lane_off = (unsigned)(col * (long)sizeof(T));
+    fo.clane_off = 0;
+    fo.pitch_bytes = (unsigned)(pitch * (long)sizeof(T));
+    fo.cpitch_bytes = 0;
+    if (interior && out_bytes < 0xFFFFF000ul) {
+        if (zero_in) fused_body<T, K, SM, false, true>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, true, fo);
+        else fused_body<T, K, SM, false, false>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, false, fo);
+    } else {
+        fused_body<T, K, SM, true>(pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, zero_in != 0, fo);
+    }
 }
 
 template <int K, int W> constexpr int fused_out_lanes() { return kWave - 2 * ((K + W - 1) / W); }
@@ -890,22 +954,25 @@ coarse_loads(PreFetch<T, VecOf<T>::W / 2>& pe, int y, const T* __restrict__ coar
 }
 
 // loads of one step of k_jacobi_cycle (whole grids: rows 0..N exist)
-template <typename T, bool EDGE>
+template <typename T, bool EDGE, bool ZIN = false>
 __device__ __forceinline__ void
 cycle_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
             const T* __restrict__ pv, const T* __restrict__ pb, long pitch, int N, int y_end, bool ld, bool zero_in,
             const CycleWin& win)
 {
     using V = typename VecOf<T>::type;
+    if constexpr (!EDGE) {
+        // interior body: no predicate, no branch (ZIN: the input is known to be all zero)
+        if constexpr (ZIN) in = vzero((V*)nullptr);
+        else in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
+        bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
+        return;
+    }
     if (EDGE) {
         // win.row_first >= 0 and win.row_last <= N: the window also keeps y inside the grid
         in = vload<V>(pv + (long)y * pitch, ld && !zero_in && y >= win.row_first && y <= win.row_last && y < y_end);
         bn = vload<V>(pb + (long)(y - 1) * pitch, ld && (y - 1) > 0 && (y - 1) < N && (y - 1) >= win.row_first &&
                                                    (y - 1) <= win.row_last && y <= y_end);
-    } else {
-        in = vzero((V*)nullptr);
-        if (!zero_in) in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
-        bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
     }
 }
 
@@ -951,17 +1018,23 @@ constexpr int ring_slot(int m) { return ((m % kBRing) + kBRing) % kBRing; }
 // register-hungry kernels of the library, a step of theirs is ~800 vector instructions long, and two
 // rows in flight keep them at two waves per SIMD without spills.
 template <bool BL, int POST> constexpr int cycle_pfd() { return (BL && POST == 1) ? 2 : kPrefetch; }
+// rows the coarse correction (PRE) is fetched ahead.  vmcnt counts in issue order, so waiting for a
+// coarse row fetched ONE step ago also waits for every fine row issued before it: with a one-step
+// coarse prefetch the three-row fine prefetch was worth one row.  The deep interior bodies fetch the
+// coarse rows as far ahead as the fine ones (8 VGPRs per extra row in double).
+template <bool BL, bool EDGE, int POST> constexpr int cycle_cpfd() { return (BL && !EDGE) ? cycle_pfd<BL, POST>() : 1; }
 
 // RP: phase of the step inside the kBRing-fold unrolled loop (BL) or inside the 3-fold one (!BL);
 // the window-rotation phase is RP % 3 either way
-template <typename T, int K, int PRE, int POST, int SM, bool EDGE, int RP, bool BL>
+template <typename T, int K, int PRE, int POST, int SM, bool EDGE, int RP, bool BL, bool ZIN>
 __device__ __forceinline__ void
 cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&bw)[BL ? 1 : K + 1], lds_vec_ptr<T> ring,
-           typename VecOf<T>::type (&nin)[kPfStages], typename VecOf<T>::type (&nbn)[kPfStages], PreFetch<T, VecOf<T>::W / 2>& pe,
+           typename VecOf<T>::type (&nin)[kPfStages], typename VecOf<T>::type (&nbn)[kPfStages], PreFetch<T, VecOf<T>::W / 2>& pe,   // pe: this step's slot
            CycleState<T, VecOf<T>::W / 2>& cs, int y,
            const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
            const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
-           long pitch, long col, long ccol, int N, const CycleArgs& ca, bool ld, bool cld, bool st, T c0, T c1)
+           long pitch, long col, long ccol, int N, const CycleArgs& ca, bool ld, bool cld, bool st, T c0, T c1,
+           const FastOut& fo)
 {
     using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
@@ -979,7 +1052,7 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     const V bn = nbn[0];
 #pragma unroll
     for (int q = 0; q + 1 < kPfStages; ++q) { nin[q] = nin[q + 1]; nbn[q] = nbn[q + 1]; }
-    cycle_loads<T, EDGE>(nin[kPfStages - 1], nbn[kPfStages - 1], y + cycle_pfd<BL, POST>(), pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win);
+    cycle_loads<T, EDGE, ZIN>(nin[kPfStages - 1], nbn[kPfStages - 1], y + cycle_pfd<BL, POST>(), pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win);
     if (PRE) {
         // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624).  The coarse
         // values of row y were fetched during the previous step (pe.a = coarse row y>>1,
@@ -987,8 +1060,20 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
         T a[CW + 1], b2[CW + 1], o[W];
 #pragma unroll
         for (int k = 0; k <= CW; ++k) { a[k] = pe.a[k]; b2[k] = pe.b[k]; }
-        coarse_loads<T, EDGE>(pe, y + 1, coarse_e, ca.cpitch, ccol, N, cld, ca.win);
-        if ((y & 1) == 0) {
+        coarse_loads<T, EDGE>(pe, y + cycle_cpfd<BL, EDGE, POST>(), coarse_e, ca.cpitch, ccol, N, cld, ca.win);
+        if constexpr (!EDGE) {
+            // branch-free: both row parities evaluated (same expressions, same order), one selected
+            const bool even = (y & 1) == 0;
+#pragma unroll
+            for (int k = 0; k < CW; ++k) {
+                const T ab = a[k] + b2[k];
+                const T ev1 = (T)0.5 * (a[k] + a[k + 1]);
+                const T od0 = (T)0.5 * ab;
+                const T od1 = (T)0.25 * ((ab + a[k + 1]) + b2[k + 1]);
+                o[2 * k] = even ? a[k] : od0;
+                o[2 * k + 1] = even ? ev1 : od1;
+            }
+        } else if ((y & 1) == 0) {
 #pragma unroll
             for (int k = 0; k < CW; ++k) { o[2 * k] = a[k]; o[2 * k + 1] = (T)0.5 * (a[k] + a[k + 1]); }
         } else {
@@ -1021,17 +1106,33 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
         for (int j = K; j > 0; --j) bw[j] = bw[j - 1];
         bw[0] = b0;
     }
-    // bw[j] = rhs row y-1-j
+    // bw[j] = rhs row y-1-j.  From the LDS ring (BL) the reads are issued kRingAhead levels before
+    // their use and pinned there: left to itself the compiler sinks every ds_read_b128 to ~5
+    // instructions in front of its consumer, and the ~100-cycle LDS latency sat exposed in every one
+    // of the K levels of the serial level-to-level chain.
+    constexpr int kRingAhead = 1;
+    constexpr int MLAST = POST ? K : K - 1;           // last window entry this step consumes
+    V rq[BL ? K + 1 : 1];                              // BL: ring values in flight (a sliding window is live)
+    if constexpr (BL) {
+        static_for<1, (kRingAhead < MLAST ? kRingAhead : MLAST) + 1>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            rq[m] = ring_get(ring, ring_slot(RP - m));
+        });
+    }
     auto bwin = [&](auto jc) -> V {
         constexpr int j = decltype(jc)::value;
         if constexpr (j == 0) return b0;
-        else if constexpr (BL) return ring_get(ring, ring_slot(RP - j));
+        else if constexpr (BL) return rq[j];
         else return bw[j];
     };
     lev[0][S_NEW] = in;
     static_for<1, K + 1>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const int row = y - j;
+        if constexpr (BL && j + kRingAhead <= MLAST) {
+            rq[j + kRingAhead] = ring_get(ring, ring_slot(RP - (j + kRingAhead)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const V cb = bwin(std::integral_constant<int, j - 1>{});
         V o;
         if constexpr (PREMUL) o = jacobi_vec_pre(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], cb, c0, c1);
@@ -1041,7 +1142,14 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
             mask_cols(o, col, N);
             if (!(row > bnd_lo && row < bnd_hi)) o = Z;
         }
-        if (j == K) vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);
+        if constexpr (j == K) {
+            if constexpr (!EDGE) {
+                const unsigned at = (unsigned)row * fo.pitch_bytes + fo.lane_off;
+                bstore(o, fo.out, (st && row >= r0 && row < r1) ? at : kOobOffset);
+            } else {
+                vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);
+            }
+        }
         if (j < K || POST) lev[j][S_NEW] = o;
     });
     if (POST) {
@@ -1053,10 +1161,14 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
             if (!(rho > bnd_lo && rho < bnd_hi)) res = Z;
         }
         if (POST == 2) {
-            if (st && rho >= r0 && rho < r1) {
-                if constexpr (W == 2) cs.acc += (double)res.x * (double)res.x + (double)res.y * (double)res.y;
-                else cs.acc += ((double)res.x * (double)res.x + (double)res.y * (double)res.y) +
-                               ((double)res.z * (double)res.z + (double)res.w * (double)res.w);
+            double r2;
+            if constexpr (W == 2) r2 = (double)res.x * (double)res.x + (double)res.y * (double)res.y;
+            else r2 = ((double)res.x * (double)res.x + (double)res.y * (double)res.y) +
+                      ((double)res.z * (double)res.z + (double)res.w * (double)res.w);
+            if constexpr (!EDGE) {
+                cs.acc += (st && rho >= r0 && rho < r1) ? r2 : 0.0;      // + 0.0 is exact: same sum, no branch
+            } else {
+                if (st && rho >= r0 && rho < r1) cs.acc += r2;
             }
         } else {
             T cl[CW], cc[CW], cr[CW];          // this row's residual left / centre / right per coarse column
@@ -1079,7 +1191,11 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
                 o[k] = wgt * ((corners + (T)2 * edges) + (T)4 * cs.mc[k]);
                 if (EDGE && (ccol + k == 0 || ccol + k >= ca.NC)) o[k] = (T)0;
             }
-            if (st && emit) {
+            if constexpr (!EDGE) {
+                const unsigned at = (st && emit) ? ((unsigned)I * fo.cpitch_bytes + fo.clane_off) : kOobOffset;
+                if constexpr (CW == 1) { bstore8(o[0], fo.cb, at); bstore8((T)0, fo.cz, at); }
+                else { bstore8(make_float2((float)o[0], (float)o[1]), fo.cb, at); bstore8(make_float2(0.f, 0.f), fo.cz, at); }
+            } else if (st && emit) {
                 T* pc = coarse_b + (long)I * ca.cpitch + ccol;
                 if constexpr (CW == 1) { pc[0] = o[0]; }
                 else { *reinterpret_cast<float2*>(pc) = make_float2((float)o[0], (float)o[1]); }
@@ -1102,12 +1218,12 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     }
 }
 
-template <typename T, int K, int PRE, int POST, int SM, bool EDGE>
+template <typename T, int K, int PRE, int POST, int SM, bool EDGE, bool ZIN = false>
 __device__ __forceinline__ double
 cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
            const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
            long pitch, long cpitch, long col, int N, int r0, int r1, bool ld, bool st, T c0, T c1, bool zero_in,
-           const CycleWin& win, lds_vec_ptr<T> ring)
+           const CycleWin& win, lds_vec_ptr<T> ring, const FastOut& fo)
 {
     constexpr bool BL = cycle_b_in_lds<T, K, POST, SM>();
     using V = typename VecOf<T>::type;
@@ -1136,28 +1252,30 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     ca.cpitch = cpitch; ca.NC = N / 2; ca.r0 = r0; ca.r1 = r1; ca.zero_in = zero_in; ca.win = win;
     const int y0 = r0 - K - ETOP;
     ca.y_end = r1 + K + EBOT;                       // exclusive end of the steps that matter
-    const int steps = (ca.y_end - y0 + 2) / 3 * 3;  // rounded up to whole rotations
+    // rounded up to whole rotations; the deep (BL) bodies run whole kBRing-step trips with no exit in
+    // between - a branch-free trip is what lets the compiler keep several rows in flight - and the
+    // launcher picks the chunk height so that nothing (or one step) is wasted
+    const int steps = BL ? (ca.y_end - y0 + kBRing - 1) / kBRing * kBRing : (ca.y_end - y0 + 2) / 3 * 3;
     constexpr int PFD = cycle_pfd<BL, POST>();
     V nin[PFD][kPfStages], nbn[PFD][kPfStages];    // [step phase mod PFD][queue position]
 #pragma unroll
     for (int q = 0; q < PFD; ++q)
-        cycle_loads<T, EDGE>(nin[q][0], nbn[q][0], y0 + q, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win);
-    PreFetch<T, CW> pe;
+        cycle_loads<T, EDGE, ZIN>(nin[q][0], nbn[q][0], y0 + q, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win);
+    constexpr int CPFD = cycle_cpfd<BL, EDGE, POST>();
+    PreFetch<T, CW> pe[CPFD];                       // [step phase mod CPFD]
 #pragma unroll
-    for (int k = 0; k <= CW; ++k) { pe.a[k] = (T)0; pe.b[k] = (T)0; }
-    if (PRE) coarse_loads<T, EDGE>(pe, y0, coarse_e, cpitch, ccol, N, cld, ca.win);
-#define MGX_CSTEP(RP, Y) cycle_step<T, K, PRE, POST, SM, EDGE, RP, BL>(lev, bw, ring, nin[(RP) % PFD], nbn[(RP) % PFD], pe, cs, Y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1)
+    for (int q = 0; q < CPFD; ++q) {
+#pragma unroll
+        for (int k = 0; k <= CW; ++k) { pe[q].a[k] = (T)0; pe[q].b[k] = (T)0; }
+        if (PRE) coarse_loads<T, EDGE>(pe[q], y0 + q, coarse_e, cpitch, ccol, N, cld, ca.win);
+    }
+#define MGX_CSTEP(RP, Y) cycle_step<T, K, PRE, POST, SM, EDGE, RP, BL, ZIN>(lev, bw, ring, nin[(RP) % PFD], nbn[(RP) % PFD], pe[(RP) % CPFD], cs, Y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1, fo)
     if constexpr (BL) {
-        // kBRing steps per trip so that every ring slot is a compile-time offset; the trip is left
-        // after any whole rotation (the step count stays a multiple of 3, not of kBRing)
-        const int yend = y0 + steps;
-        for (int y = y0; y < yend; y += kBRing) {
+        // kBRing steps per trip so that every ring slot is a compile-time offset
+        for (int y = y0; y < y0 + steps; y += kBRing) {
             MGX_CSTEP(0, y); MGX_CSTEP(1, y + 1); MGX_CSTEP(2, y + 2);
-            if (y + 3 >= yend) break;
             MGX_CSTEP(3, y + 3); MGX_CSTEP(4, y + 4); MGX_CSTEP(5, y + 5);
-            if (y + 6 >= yend) break;
             MGX_CSTEP(6, y + 6); MGX_CSTEP(7, y + 7); MGX_CSTEP(8, y + 8);
-            if (y + 9 >= yend) break;
             MGX_CSTEP(9, y + 9); MGX_CSTEP(10, y + 10); MGX_CSTEP(11, y + 11);
         }
     } else {
@@ -1206,16 +1324,36 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         // everything the unpredicated body touches (rows r0-K-ETOP-1 .. r1+K+EBOT+1+kPrefetch:
         // rotation rounding plus the prefetched rows; one vector beyond the first and last lane;
         // the matching coarse rows/columns) strictly inside the grid and inside the window
-        const int y_first = r0 - K - ETOP - 1, y_lastp = r1 + K + EBOT + 1 + kPrefetch;
+        // (the deep bodies round their step count up to whole kBRing-step trips)
+        constexpr int kRound = BL ? kBRing : 3;
+        const int y_first = r0 - K - ETOP - 1;
+        const int y_lastp = (r0 - K - ETOP) + ((r1 + K + EBOT) - (r0 - K - ETOP) + kRound - 1) / kRound * kRound + kPrefetch;
         bool interior = (vx0 >= 1) && ((long)(vx0 + kWave + 1) * W < N) &&
                         (y_first > 0) && (y_lastp < N) && (y_first >= win.row_first) && (y_lastp <= win.row_last);
         if (PRE) interior = interior && (y_first >> 1) >= win.crow_first && ((y_lastp >> 1) + 1) <= win.crow_last;
-        if (interior)
-            acc = cycle_body<T, K, PRE, POST, SM, false>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
-                                                         pitch, cpitch, col, N, r0, r1, true, st, c0, c1, zero_in != 0, win, ring);
-        else
+        // the interior bodies store through 32-bit buffer offsets: the rows that exist must end below 4 GiB
+        const unsigned long out_bytes = (unsigned long)(win.row_last + 1) * (unsigned long)pitch * sizeof(T);
+        const unsigned long cb_bytes = (unsigned long)(win.crow_last + 1) * (unsigned long)cpitch * sizeof(T);
+        interior = interior && out_bytes < 0xFFFFF000ul && !(PRE != 0 && zero_in);
+        FastOut fo;
+        fo.out = make_rsrc(vout, (unsigned)out_bytes);
+        fo.cb = make_rsrc(coarse_b, (POST == 1 && coarse_b) ? (unsigned)cb_bytes : 0u);
+        fo.cz = make_rsrc(coarse_zero, (POST == 1 && coarse_zero) ? (unsigned)cb_bytes : 0u);   // empty: every store dropped
+        fo.lane_off = (unsigned)(col * (long)sizeof(T));
+        fo.clane_off = (unsigned)((col / 2) * (long)sizeof(T));
+        fo.pitch_bytes = (unsigned)(pitch * (long)sizeof(T));
+        fo.cpitch_bytes = (unsigned)(cpitch * (long)sizeof(T));
+        if (interior) {
+            if (PRE == 0 && zero_in)
+                acc = cycle_body<T, K, PRE, POST, SM, false, PRE == 0>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
+                                                                      pitch, cpitch, col, N, r0, r1, true, st, c0, c1, true, win, ring, fo);
+            else
+                acc = cycle_body<T, K, PRE, POST, SM, false, false>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
+                                                                    pitch, cpitch, col, N, r0, r1, true, st, c0, c1, false, win, ring, fo);
+        } else {
             acc = cycle_body<T, K, PRE, POST, SM, true>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
-                                                        pitch, cpitch, col, N, r0, r1, ld, st, c0, c1, zero_in != 0, win, ring);
+                                                        pitch, cpitch, col, N, r0, r1, ld, st, c0, c1, zero_in != 0, win, ring, fo);
+        }
     }
     if (POST == 2) {
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);

@@ -286,6 +286,18 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
 {
     constexpr int OUT = cycle_out_lanes<K, POST, VecOf<T>::W>();
     if (R & 1) ++R;                                    // chunks must start on odd rows (POST = 1)
+    if constexpr (cycle_b_in_lds<T, K, POST, SM>()) {
+        // the deep bodies run whole kBRing-step trips: a chunk is R + 2K + (stage rows) steps long, so
+        // take the next even R that makes it a multiple of kBRing (or one short of it)
+        constexpr int E = POST == 1 ? 3 : (POST == 2 ? 2 : 0);
+        int best = R;
+        for (int r = R; r < R + 2 * kBRing; r += 2) {
+            const int m = (r + 2 * K + E) % kBRing;
+            if (m == 0) { best = r; break; }
+            if (m == kBRing - 1 && best == R) best = r;
+        }
+        R = best;
+    }
     const bool whole = (fa.row_hi == 0);
     const int row_lo = whole ? 1 : fa.row_lo, row_hi = whole ? N : fa.row_hi;
     const CycleWin win = whole ? CycleWin{0, N, 0, N / 2, 1, N / 2} : fa.win;
