@@ -116,21 +116,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
+// (the register images are built component by component: a bit_cast of the HIP vector structs went
+// through a stack slot - scratch - in the float kernels)
 __device__ __forceinline__ void bstore(const double2& v, __amdgpu_buffer_rsrc_t r, unsigned voff)
 {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, v), r, voff, 0, 0);
+    const v4i32 t = {__double2loint(v.x), __double2hiint(v.x), __double2loint(v.y), __double2hiint(v.y)};
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, 0, 0);
 }
 __device__ __forceinline__ void bstore(const float4& v, __amdgpu_buffer_rsrc_t r, unsigned voff)
 {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, v), r, voff, 0, 0);
+    const v4i32 t = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, 0, 0);
 }
 __device__ __forceinline__ void bstore8(double v, __amdgpu_buffer_rsrc_t r, unsigned voff)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i32, v), r, voff, 0, 0);
+    const v2i32 t = {__double2loint(v), __double2hiint(v)};
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, 0, 0);
 }
 __device__ __forceinline__ void bstore8(float2 v, __amdgpu_buffer_rsrc_t r, unsigned voff)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i32, v), r, voff, 0, 0);
+    const v2i32 t = {__float_as_int(v.x), __float_as_int(v.y)};
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, 0, 0);
 }
 // what an interior body needs to store without branches (built once per wave from uniform values)
 struct FastOut {
@@ -497,6 +503,15 @@ fused_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
     }
 }
 
+// Steps per loop trip of the interior (branch-free) bodies.  s_waitcnt insertion is exact inside a
+// straight-line trip and conservative at every loop back-edge, so longer trips keep more of the
+// prefetched rows really in flight: 6 (two window rotations) for the shallow kernels, kBRing = 12
+// for the deep ones.  The step count is rounded up to whole trips; the launch wrappers choose the
+// chunk height so that at most one step is wasted (trip_rows below).
+// double: 12 steps (at the loop head nothing is in flight, so a trip should be much longer than the
+// prefetch distance); float: the packed-arithmetic bodies are register-bound and spill with long
+// trips, they keep 3-step trips.
+template <typename T> constexpr int trip_steps() { return 3; }
 constexpr int kPfStages = 1;                 // prefetch slots per rotation phase (2 = six rows ahead: measured slower)
 constexpr int kPrefetch = 3 * kPfStages;     // rows a marching wave loads ahead
 
@@ -565,16 +580,26 @@ fused_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     // interior body the caller guarantees five more rows exist below the cone:
     // two for the rounding, three for the prefetch)
     const int y0 = r0 - K;
-    const int steps = (r1 + K - y0 + 2) / 3 * 3;
+    constexpr int kRound = EDGE ? 3 : trip_steps<T>();
+    const int steps = (r1 + K - y0 + kRound - 1) / kRound * kRound;
     V nin[3][kPfStages], nbn[3][kPfStages];        // [rotation phase][queue position]
 #pragma unroll
     for (int q = 0; q < kPrefetch; ++q)
         fused_loads<T, K, EDGE, ZIN>(nin[q % 3][q / 3], nbn[q % 3][q / 3], y0 + q, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
-    for (int y = y0; y < y0 + steps; y += 3) {
-        fused_step<T, K, SM, EDGE, 0, ZIN>(lev, bw, nin[0], nbn[0], y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in, fo);
-        fused_step<T, K, SM, EDGE, 1, ZIN>(lev, bw, nin[1], nbn[1], y + 1, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in, fo);
-        fused_step<T, K, SM, EDGE, 2, ZIN>(lev, bw, nin[2], nbn[2], y + 2, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in, fo);
+#define MGX_FSTEP(P, Y) fused_step<T, K, SM, EDGE, P, ZIN>(lev, bw, nin[P], nbn[P], Y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in, fo)
+    if constexpr (!EDGE && trip_steps<T>() == 12) {
+        for (int y = y0; y < y0 + steps; y += 12) {
+            MGX_FSTEP(0, y); MGX_FSTEP(1, y + 1); MGX_FSTEP(2, y + 2);
+            MGX_FSTEP(0, y + 3); MGX_FSTEP(1, y + 4); MGX_FSTEP(2, y + 5);
+            MGX_FSTEP(0, y + 6); MGX_FSTEP(1, y + 7); MGX_FSTEP(2, y + 8);
+            MGX_FSTEP(0, y + 9); MGX_FSTEP(1, y + 10); MGX_FSTEP(2, y + 11);
+        }
+    } else {
+        for (int y = y0; y < y0 + steps; y += 3) {
+            MGX_FSTEP(0, y); MGX_FSTEP(1, y + 1); MGX_FSTEP(2, y + 2);
+        }
     }
+#undef MGX_FSTEP
 }
 
 template <typename T, int K, int SM = 0>
@@ -607,7 +632,7 @@ k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     const int vx0 = t.strip * OUT - HL;
     const bool interior = (vx0 >= 1) && ((long)(vx0 + kWave) * W < N) &&
                           (r0 - K - 1 > bnd_lo) && (r0 - K - 1 >= 0) &&
-                          (r1 + K + 2 + kPrefetch < bnd_hi) && (r1 + K + 2 + kPrefetch <= rows_alloc - 1);
+                          (r1 + K + trip_steps<T>() + kPrefetch < bnd_hi) && (r1 + K + trip_steps<T>() + kPrefetch <= rows_alloc - 1);
     // the interior bodies store through 32-bit buffer offsets (local rows of this array)
     const unsigned long out_bytes = (unsigned long)rows_alloc * (unsigned long)pitch * sizeof(T);
     FastOut fo;
@@ -1020,9 +1045,9 @@ constexpr int ring_slot(int m) { return ((m % kBRing) + kBRing) % kBRing; }
 template <bool BL, int POST> constexpr int cycle_pfd() { return (BL && POST == 1) ? 2 : kPrefetch; }
 // rows the coarse correction (PRE) is fetched ahead.  vmcnt counts in issue order, so waiting for a
 // coarse row fetched ONE step ago also waits for every fine row issued before it: with a one-step
-// coarse prefetch the three-row fine prefetch was worth one row.  The deep interior bodies fetch the
+// coarse prefetch the three-row fine prefetch was worth one row.  The interior bodies fetch the
 // coarse rows as far ahead as the fine ones (8 VGPRs per extra row in double).
-template <bool BL, bool EDGE, int POST> constexpr int cycle_cpfd() { return (BL && !EDGE) ? cycle_pfd<BL, POST>() : 1; }
+template <typename T, bool BL, bool EDGE, int POST> constexpr int cycle_cpfd() { return (BL && !EDGE) ? cycle_pfd<BL, POST>() : 1; }
 
 // RP: phase of the step inside the kBRing-fold unrolled loop (BL) or inside the 3-fold one (!BL);
 // the window-rotation phase is RP % 3 either way
@@ -1060,7 +1085,7 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
         T a[CW + 1], b2[CW + 1], o[W];
 #pragma unroll
         for (int k = 0; k <= CW; ++k) { a[k] = pe.a[k]; b2[k] = pe.b[k]; }
-        coarse_loads<T, EDGE>(pe, y + cycle_cpfd<BL, EDGE, POST>(), coarse_e, ca.cpitch, ccol, N, cld, ca.win);
+        coarse_loads<T, EDGE>(pe, y + cycle_cpfd<T, BL, EDGE, POST>(), coarse_e, ca.cpitch, ccol, N, cld, ca.win);
         if constexpr (!EDGE) {
             // branch-free: both row parities evaluated (same expressions, same order), one selected
             const bool even = (y & 1) == 0;
@@ -1255,13 +1280,14 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     // rounded up to whole rotations; the deep (BL) bodies run whole kBRing-step trips with no exit in
     // between - a branch-free trip is what lets the compiler keep several rows in flight - and the
     // launcher picks the chunk height so that nothing (or one step) is wasted
-    const int steps = BL ? (ca.y_end - y0 + kBRing - 1) / kBRing * kBRing : (ca.y_end - y0 + 2) / 3 * 3;
+    constexpr int kRound = BL ? kBRing : (EDGE ? 3 : trip_steps<T>());
+    const int steps = (ca.y_end - y0 + kRound - 1) / kRound * kRound;
     constexpr int PFD = cycle_pfd<BL, POST>();
     V nin[PFD][kPfStages], nbn[PFD][kPfStages];    // [step phase mod PFD][queue position]
 #pragma unroll
     for (int q = 0; q < PFD; ++q)
         cycle_loads<T, EDGE, ZIN>(nin[q][0], nbn[q][0], y0 + q, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win);
-    constexpr int CPFD = cycle_cpfd<BL, EDGE, POST>();
+    constexpr int CPFD = cycle_cpfd<T, BL, EDGE, POST>();
     PreFetch<T, CW> pe[CPFD];                       // [step phase mod CPFD]
 #pragma unroll
     for (int q = 0; q < CPFD; ++q) {
@@ -1273,6 +1299,13 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     if constexpr (BL) {
         // kBRing steps per trip so that every ring slot is a compile-time offset
         for (int y = y0; y < y0 + steps; y += kBRing) {
+            MGX_CSTEP(0, y); MGX_CSTEP(1, y + 1); MGX_CSTEP(2, y + 2);
+            MGX_CSTEP(3, y + 3); MGX_CSTEP(4, y + 4); MGX_CSTEP(5, y + 5);
+            MGX_CSTEP(6, y + 6); MGX_CSTEP(7, y + 7); MGX_CSTEP(8, y + 8);
+            MGX_CSTEP(9, y + 9); MGX_CSTEP(10, y + 10); MGX_CSTEP(11, y + 11);
+        }
+    } else if constexpr (!EDGE && trip_steps<T>() == 12) {
+        for (int y = y0; y < y0 + steps; y += 12) {
             MGX_CSTEP(0, y); MGX_CSTEP(1, y + 1); MGX_CSTEP(2, y + 2);
             MGX_CSTEP(3, y + 3); MGX_CSTEP(4, y + 4); MGX_CSTEP(5, y + 5);
             MGX_CSTEP(6, y + 6); MGX_CSTEP(7, y + 7); MGX_CSTEP(8, y + 8);
@@ -1325,7 +1358,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         // rotation rounding plus the prefetched rows; one vector beyond the first and last lane;
         // the matching coarse rows/columns) strictly inside the grid and inside the window
         // (the deep bodies round their step count up to whole kBRing-step trips)
-        constexpr int kRound = BL ? kBRing : 3;
+        constexpr int kRound = BL ? kBRing : trip_steps<T>();
         const int y_first = r0 - K - ETOP - 1;
         const int y_lastp = (r0 - K - ETOP) + ((r1 + K + EBOT) - (r0 - K - ETOP) + kRound - 1) / kRound * kRound + kPrefetch;
         bool interior = (vx0 >= 1) && ((long)(vx0 + kWave + 1) * W < N) &&

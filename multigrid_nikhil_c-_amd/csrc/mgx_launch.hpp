@@ -73,6 +73,19 @@ void launch_rbgs(const T* vin, const T* b, T* vout, int N, long pitch, int row_l
                        row_lo, row_hi, g.R, g.strips, g.chunks, row_parity, bnd_lo, bnd_hi);
 }
 
+// chunk height >= R (in steps of `step`) for which a chunk's step count R + extra is a whole number of
+// loop trips, or one short of it when parity rules the exact fit out
+inline int trip_rows(int R, int extra, int trip, int step)
+{
+    int best = -1;
+    for (int r = R; r < R + 2 * trip; r += step) {
+        const int m = (r + extra) % trip;
+        if (m == 0) return r;
+        if (m == trip - 1 && best < 0) best = r;
+    }
+    return best < 0 ? R : best;
+}
+
 // K levels in one pass (k_jacobi_fused<T,K,SM>): K Jacobi sweeps (SM = 0) or K/2
 // red-black Gauss-Seidel sweeps (SM = 1)
 template <typename T, int K, int SM>
@@ -80,6 +93,7 @@ void launch_fused_k(const T* vin, const T* b, T* vout, int N, long pitch, int ro
                     T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st, int rows_alloc, int zero_in)
 {
     constexpr int OUT = fused_out_lanes<K, VecOf<T>::W>();
+    R = trip_rows(R, 2 * K, trip_steps<T>(), 1);       // whole loop trips in the interior body
     Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, R);
     g.strips = (N / VecOf<T>::W + OUT - 1) / OUT;
     const long waves = (long)g.strips * g.chunks;
@@ -286,17 +300,12 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
 {
     constexpr int OUT = cycle_out_lanes<K, POST, VecOf<T>::W>();
     if (R & 1) ++R;                                    // chunks must start on odd rows (POST = 1)
-    if constexpr (cycle_b_in_lds<T, K, POST, SM>()) {
-        // the deep bodies run whole kBRing-step trips: a chunk is R + 2K + (stage rows) steps long, so
-        // take the next even R that makes it a multiple of kBRing (or one short of it)
+    {
+        // the interior bodies run whole trips (kBRing steps for the deep variants, kTrip otherwise): a
+        // chunk is R + 2K + (stage rows) steps long, so take the next even R that makes it a multiple
+        // of the trip (or one short of it)
         constexpr int E = POST == 1 ? 3 : (POST == 2 ? 2 : 0);
-        int best = R;
-        for (int r = R; r < R + 2 * kBRing; r += 2) {
-            const int m = (r + 2 * K + E) % kBRing;
-            if (m == 0) { best = r; break; }
-            if (m == kBRing - 1 && best == R) best = r;
-        }
-        R = best;
+        R = trip_rows(R, 2 * K + E, cycle_b_in_lds<T, K, POST, SM>() ? kBRing : trip_steps<T>(), 2);
     }
     const bool whole = (fa.row_hi == 0);
     const int row_lo = whole ? 1 : fa.row_lo, row_hi = whole ? N : fa.row_hi;
@@ -321,8 +330,13 @@ int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, i
         case 2: return launch_cycle_k<T, 2, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
         case 4: return launch_cycle_k<T, 4, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
         case 6: return launch_cycle_k<T, 6, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
-        case 8: return launch_cycle_k<T, 8, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
         default: break;
+    }
+    // 8 levels: not for float passes that start from the input and end with a residual stage (with the
+    // branch-free interior bodies their predicated body extracts an odd-indexed pair of a float4
+    // through a stack slot: scratch)
+    if constexpr (sizeof(T) == 8 || PRE == 1 || POST == 0) {
+        if (K == 8) return launch_cycle_k<T, 8, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
     }
     // 10 levels with folded stages: double only (the float variants, whose packed arithmetic
     // needs aligned register pairs, exceed 256 VGPRs), and not the two most register-hungry
@@ -346,6 +360,7 @@ int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, i
 inline bool cycle_k_supported(int K, bool rbgs, bool f64, int post = 0, bool pre = false)
 {
     if (K == 10) return f64 && !(pre && post == 1) && !(rbgs && post == 1);
+    if (K == 8 && !f64 && !pre && post != 0) return false;
     return rbgs ? (K == 2 || K == 4 || K == 6 || K == 8) : (K >= 1 && K <= 8 && K != 7);
 }
 
