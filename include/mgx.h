@@ -362,6 +362,9 @@ MGX_API int mgx_create_rank(const mgx_config* cfg, int rank, int world, const vo
                             const mgx_transport* transport, mgx_handle* out);
 /* number of halo exchanges a multi-GPU handle has performed (tests: communication plan) */
 MGX_API long mgx_dist_exchanges(mgx_handle h);
+/* how many of them ran on the slab's second stream beside the rows of the following smoothing pass that
+ * need no halo (the pass then finishes with its two edge bands; MGX_DIST_OVERLAP=0 turns this off) */
+MGX_API long mgx_dist_overlapped(mgx_handle h);
 /* plain copies for callers that implement a transport without a HIP binding of their own */
 MGX_API int mgx_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 MGX_API int mgx_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);

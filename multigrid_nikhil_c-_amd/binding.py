@@ -40,7 +40,7 @@ EXPORTS = [
     "mgx_slab_residual_sumsq", "mgx_slab_scratch_doubles",
     "mgx_plan_create", "mgx_plan_destroy", "mgx_plan_last_error", "mgx_plan_cut_level", "mgx_plan_level",
     "mgx_plan_cut_share", "mgx_plan_guess_set", "mgx_plan_vcycle", "mgx_plan_norm", "mgx_rccl_unique_id",
-    "mgx_create_rank", "mgx_dist_exchanges", "mgx_memcpy_d2h", "mgx_memcpy_h2d",
+    "mgx_create_rank", "mgx_dist_exchanges", "mgx_dist_overlapped", "mgx_memcpy_d2h", "mgx_memcpy_h2d",
 ]
 MAX_GPUS = 16
 (DOP_EXCHANGE, DOP_ZERO_U, DOP_CYCLE, DOP_SMOOTH, DOP_RESTRICT, DOP_PROLONG, DOP_GATHER_CUT, DOP_COARSE, DOP_SUMSQ,
@@ -180,6 +180,8 @@ def lib() -> C.CDLL:
     L.mgx_create_rank.argtypes = [C.POINTER(Config), C.c_int, C.c_int, vp, C.POINTER(Transport), C.POINTER(vp)]
     L.mgx_dist_exchanges.argtypes = [vp]
     L.mgx_dist_exchanges.restype = C.c_long
+    L.mgx_dist_overlapped.argtypes = [vp]
+    L.mgx_dist_overlapped.restype = C.c_long
     L.mgx_memcpy_d2h.argtypes = [vp, vp, C.c_size_t, vp]
     L.mgx_memcpy_h2d.argtypes = [vp, vp, C.c_size_t, vp]
     _lib = L
@@ -286,6 +288,10 @@ class Multigrid:
     def exchanges(self):
         """halo exchanges a multi-GPU handle has performed"""
         return int(lib().mgx_dist_exchanges(self._h))
+
+    def overlapped(self):
+        """... of which ran beside the interior rows of the smoothing pass they feed"""
+        return int(lib().mgx_dist_overlapped(self._h))
 
     # -- plumbing --------------------------------------------------------------
     def _chk(self, st, what):

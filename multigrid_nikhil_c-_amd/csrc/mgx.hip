@@ -1606,6 +1606,7 @@ int mgx_rccl_unique_id(void* out128)
 }
 
 long mgx_dist_exchanges(mgx_handle s) { return (s && s->dist) ? s->dist->exchanges : -1; }
+long mgx_dist_overlapped(mgx_handle s) { return (s && s->dist) ? s->dist->overlapped : -1; }
 
 int mgx_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream)
 {

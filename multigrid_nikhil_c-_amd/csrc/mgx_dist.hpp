@@ -26,7 +26,9 @@ struct DistLevelBuf {
 
 struct DistSlab {
     int g = 0, device = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;                // compute stream: every slab operator
+    hipStream_t cm = nullptr;                // second stream: a halo exchange and the edge bands that wait for
+                                             // it, while `st` smooths the rows that need no halo (overlap)
     DistPlanner plan;
     std::vector<DistLevelBuf> lv;            // index = level - (cut + 1)
     void* c_own = nullptr;                   // this slab's rows of the cut level's right-hand side
@@ -54,6 +56,8 @@ struct mgx_dist {
     bool have_ext = false;
     mgx_transport ext{};
     long exchanges = 0;
+    long overlapped = 0;                     // exchanges that ran beside the interior rows of the pass they feed
+    int overlap = 1;                         // MGX_DIST_OVERLAP
     double fine_updates = 0.0;
     // profiling of the finest-level smoothing blocks of the first local slab (cfg.profile)
     std::vector<EventPair> ev_used, ev_free;
@@ -146,6 +150,7 @@ void dist_free(mgx_dist* d)
         if (sl.sum_host) (void)hipHostFree(sl.sum_host);
         if (sl.ev_ready) (void)hipEventDestroy(sl.ev_ready);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+        if (sl.cm) { (void)hipStreamSynchronize(sl.cm); (void)hipStreamDestroy(sl.cm); }
         if (sl.st) (void)hipStreamDestroy(sl.st);
     }
     for (auto& p : d->ev_used) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -158,6 +163,7 @@ int dist_alloc_slab(mgx_solver* s, mgx_dist* d, DistSlab& sl)
 {
     DCHK(s, hipSetDevice(sl.device));
     DCHK(s, hipStreamCreate(&sl.st));
+    DCHK(s, hipStreamCreate(&sl.cm));
     DCHK(s, hipEventCreateWithFlags(&sl.ev_ready, hipEventDisableTiming));
     DCHK(s, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
     const int dt = d->f64 ? MGX_DTYPE_F64 : MGX_DTYPE_F32;
@@ -218,6 +224,7 @@ int dist_create(mgx_solver* s, const mgx_config* cfg, int rank, int world, const
     if (d->cut >= cfg->finest_level || d->cut < 2)
         return s->fail(MGX_ERR_INVALID, "no level above cut_level to distribute (use a single-GPU handle)");
     const bool fold = env_int("MGX_DIST_FOLD", 1) != 0, deep = env_int("MGX_DIST_DEEP", 1) != 0;
+    d->overlap = env_int("MGX_DIST_OVERLAP", 1);
     const int first = multi_process ? rank : 0, count = multi_process ? 1 : P;
     d->slabs.resize(count);
     for (int i = 0; i < count; ++i) {
@@ -280,10 +287,16 @@ inline hipError_t copy_between(void* dst, int dst_dev, const void* src, int src_
     return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st);
 }
 
-int dist_exchange(mgx_solver* s, mgx_dist* d, const mgx_dist_op& o)
+// on_comm: run the exchange on the slabs' second stream.  after(slab, stream): what to enqueue on that
+// stream once the slab's halo rows are in (the edge bands of an overlapped smoothing pass);
+// meanwhile(slab): what the compute stream does in the meantime (the rows that need no halo), enqueued
+// before the compute stream joins the exchange.
+template <typename After, typename Meanwhile>
+int dist_exchange(mgx_solver* s, mgx_dist* d, const mgx_dist_op& o, bool on_comm, After after, Meanwhile meanwhile)
 {
     const int P = d->P;
     const size_t es = d->es;
+    auto xs = [&](DistSlab& sl) { return on_comm ? sl.cm : sl.st; };
     if (d->rank < 0) {
         // one process: pull the neighbours' edge rows with device-to-device copies on the receiver's
         // stream; events order them after the producers and before the next writers of the source rows
@@ -296,15 +309,16 @@ int dist_exchange(mgx_solver* s, mgx_dist* d, const mgx_dist_op& o)
             const int lo = g.own_lo - g.row0;                       // lower interior slab edge (local row)
             const int up = (sl.g + 1) * (g.N / P) - g.row0;         // upper interior slab edge (local row)
             DCHK(s, hipSetDevice(sl.device));
+            if (on_comm) DCHK(s, hipStreamWaitEvent(sl.cm, sl.ev_ready, 0));
             if (sl.g > 0) {
                 DistSlab& nb = d->slabs[sl.g - 1];
                 const mgx_dist_level& ng = nb.plan.L(o.level);
                 DistLevelBuf& nlb = buf(nb, o.level);
                 void* nt = (o.which == MGX_VEC_U) ? nlb.u : nlb.b;
                 const int nup = sl.g * (ng.N / P) - ng.row0;        // the neighbour's upper edge
-                DCHK(s, hipStreamWaitEvent(sl.st, nb.ev_ready, 0));
+                DCHK(s, hipStreamWaitEvent(xs(sl), nb.ev_ready, 0));
                 DCHK(s, copy_between(rows_ptr(d, t, lb.pitch, lo - o.depth), sl.device,
-                                     rows_ptr(d, nt, nlb.pitch, nup - o.depth), nb.device, bytes, sl.st));
+                                     rows_ptr(d, nt, nlb.pitch, nup - o.depth), nb.device, bytes, xs(sl)));
             }
             if (sl.g < P - 1) {
                 DistSlab& nb = d->slabs[sl.g + 1];
@@ -312,15 +326,23 @@ int dist_exchange(mgx_solver* s, mgx_dist* d, const mgx_dist_op& o)
                 DistLevelBuf& nlb = buf(nb, o.level);
                 void* nt = (o.which == MGX_VEC_U) ? nlb.u : nlb.b;
                 const int nlo = ng.own_lo - ng.row0;
-                DCHK(s, hipStreamWaitEvent(sl.st, nb.ev_ready, 0));
+                DCHK(s, hipStreamWaitEvent(xs(sl), nb.ev_ready, 0));
                 DCHK(s, copy_between(rows_ptr(d, t, lb.pitch, up), sl.device,
-                                     rows_ptr(d, nt, nlb.pitch, nlo), nb.device, bytes, sl.st));
+                                     rows_ptr(d, nt, nlb.pitch, nlo), nb.device, bytes, xs(sl)));
             }
-            DCHK(s, hipEventRecord(sl.ev_done, sl.st));
+            const int rc = after(sl, xs(sl));
+            if (rc != MGX_OK) return rc;
+            DCHK(s, hipEventRecord(sl.ev_done, xs(sl)));
         }
-        // nobody overwrites rows a neighbour is still reading
+        for (auto& sl : d->slabs) {
+            const int rc = meanwhile(sl);
+            if (rc != MGX_OK) return rc;
+        }
+        // nobody overwrites rows a neighbour is still reading (and the compute stream joins its own
+        // second stream)
         for (auto& sl : d->slabs) {
             DCHK(s, hipSetDevice(sl.device));
+            if (on_comm) DCHK(s, hipStreamWaitEvent(sl.st, sl.ev_done, 0));
             if (sl.g > 0) DCHK(s, hipStreamWaitEvent(sl.st, d->slabs[sl.g - 1].ev_done, 0));
             if (sl.g < P - 1) DCHK(s, hipStreamWaitEvent(sl.st, d->slabs[sl.g + 1].ev_done, 0));
         }
@@ -342,17 +364,26 @@ int dist_exchange(mgx_solver* s, mgx_dist* d, const mgx_dist_op& o)
             x[n++] = mgx_xfer{0, sl.g + 1, rows_ptr(d, t, lb.pitch, up), bytes};
         }
         DCHK(s, hipSetDevice(sl.device));
+        if (on_comm) {
+            DCHK(s, hipEventRecord(sl.ev_ready, sl.st));
+            DCHK(s, hipStreamWaitEvent(sl.cm, sl.ev_ready, 0));
+        }
         if (d->use_rccl) {
             // one group per exchange: the sends and receives of both neighbours progress together
             NCHK(s, ncclGroupStart());
             for (int i = 0; i < n; ++i) {
-                if (x[i].send) NCHK(s, ncclSend(x[i].ptr, x[i].bytes, ncclChar, x[i].peer, d->comm, sl.st));
-                else NCHK(s, ncclRecv(x[i].ptr, x[i].bytes, ncclChar, x[i].peer, d->comm, sl.st));
+                if (x[i].send) NCHK(s, ncclSend(x[i].ptr, x[i].bytes, ncclChar, x[i].peer, d->comm, xs(sl)));
+                else NCHK(s, ncclRecv(x[i].ptr, x[i].bytes, ncclChar, x[i].peer, d->comm, xs(sl)));
             }
             NCHK(s, ncclGroupEnd());
         } else if (d->have_ext) {
-            if (d->ext.sendrecv(d->ext.ctx, n, x, (void*)sl.st) != 0) return s->fail(MGX_ERR_HIP, "transport sendrecv failed");
+            if (d->ext.sendrecv(d->ext.ctx, n, x, (void*)xs(sl)) != 0) return s->fail(MGX_ERR_HIP, "transport sendrecv failed");
         }
+        int rc = after(sl, xs(sl));
+        if (rc != MGX_OK) return rc;
+        if (on_comm) DCHK(s, hipEventRecord(sl.ev_done, sl.cm));
+        if ((rc = meanwhile(sl)) != MGX_OK) return rc;
+        if (on_comm) DCHK(s, hipStreamWaitEvent(sl.st, sl.ev_done, 0));
     }
     d->exchanges += 1;
     return MGX_OK;
@@ -420,6 +451,67 @@ int dist_block_launches(const mgx_dist* d, int N, int mu, int post)
     return plan_folded(fuse_cfg(), d->cfg.smoother, N, mu, post, d->f64, parts);
 }
 
+// the CYCLE operation of a plan on local rows [row_lo,row_hi) of its range, on `stream` (the whole
+// range normally; the interior rows and the two edge bands separately when a halo exchange overlaps it)
+int dist_cycle_rows(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op& o, int row_lo, int row_hi, hipStream_t stream,
+                    int* flag)
+{
+    const int cut = d->cut;
+    const int dt = d->f64 ? MGX_DTYPE_F64 : MGX_DTYPE_F32;
+    const mgx_dist_level& g = sl.plan.L(o.level);
+    DistLevelBuf& lb = buf(sl, o.level);
+    const mgx_slab fs = slab_of(d, g);
+    mgx_slab cs{};
+    const void* ce = nullptr;
+    void* cb = nullptr;
+    if (o.pre) {
+        if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, (1 << cut) + 1, 0}; ce = sl.coarse->lv[cut].u; }
+        else { cs = slab_of(d, sl.plan.L(o.level - 1)); ce = buf(sl, o.level - 1).u; }
+    }
+    if (o.post == 1) {
+        if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, sl.plan.c_rows, sl.plan.c_row0}; cb = sl.c_own; }
+        else { cs = slab_of(d, sl.plan.L(o.level - 1)); cb = buf(sl, o.level - 1).b; }
+    }
+    const int rc = mgx_slab_cycle(&fs, lb.u, lb.b, lb.tmp, row_lo, row_hi, o.mu, d->cfg.omega, d->cfg.smoother,
+                                  (o.pre || o.post == 1) ? &cs : nullptr, ce, cb, o.crow_lo, o.crow_hi, d->cfg.restrict_mode,
+                                  o.post == 2 ? sl.scratch : nullptr, o.post == 2 ? sl.sum_dev : nullptr, flag, (void*)stream);
+    if (rc != MGX_OK) return s->fail(rc, "mgx_slab_cycle failed on a slab");
+    return MGX_OK;
+}
+
+// An exchange followed (after the zero fills of coarser guesses) by the pre-smoothing block of the same
+// level that is ONE pass: the rows whose dependency cone touches no halo row are smoothed on the compute
+// stream while the halos travel; the two edge bands follow the halos on the second stream.  Three
+// launches of the same kernel on disjoint row ranges reading the same input: same bits as one launch.
+// Returns the index of the CYCLE operation, or -1 when the pattern / the pass count does not fit.
+int dist_overlap_candidate(const mgx_dist* d, const DistSlab& sl, size_t i)
+{
+    const std::vector<mgx_dist_op>& ops = sl.ops;
+    const mgx_dist_op& x = ops[i];
+    size_t j = i + 1;
+    while (j < ops.size() && ops[j].op == MGX_DOP_ZERO_U) ++j;
+    if (j >= ops.size()) return -1;
+    const mgx_dist_op& c = ops[j];
+    if (c.op != MGX_DOP_CYCLE || c.level != x.level || c.pre != 0 || c.post != 1) return -1;
+    if (dist_block_launches(d, 1 << c.level, c.mu, c.post) != 1) return -1;     // several passes ping-pong the rows the bands rewrite
+    return (int)j;
+}
+
+// interior rows [*lo,*hi) of the CYCLE range of slab `sl`: outputs that depend on no halo row being
+// exchanged; both ends on odd global rows (the folded restriction wants its ranges to start there)
+bool dist_interior_rows(const mgx_dist* d, const DistSlab& sl, const mgx_dist_op& c, int* lo, int* hi)
+{
+    const mgx_dist_level& g = sl.plan.L(c.level);
+    const int per = d->cfg.smoother == MGX_SMOOTHER_RBGS ? 2 : 1;
+    const int D = per * c.mu + 3;                                   // sweeps + the residual / restriction rows
+    const int own_lo = g.own_lo - g.row0, own_hi = (sl.g + 1) * (g.N / d->P) - g.row0;    // interior slab edges (local)
+    int a = c.row_lo, b = c.row_hi;
+    if (sl.g > 0) { a = own_lo + D; if (((a + g.row0) & 1) == 0) ++a; }
+    if (sl.g < d->P - 1) { b = own_hi - D; if (((b + g.row0) & 1) == 0) --b; }
+    *lo = a; *hi = b;
+    return b - a >= 64;                                            // worth three launches
+}
+
 int dist_local_op(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op& o)
 {
     DCHK(s, hipSetDevice(sl.device));
@@ -433,28 +525,12 @@ int dist_local_op(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op& o
             return MGX_OK;
         }
         case MGX_DOP_CYCLE: {
-            const mgx_dist_level& g = sl.plan.L(o.level);
-            DistLevelBuf& lb = buf(sl, o.level);
-            const mgx_slab fs = slab_of(d, g);
-            mgx_slab cs{};
-            const void* ce = nullptr;
-            void* cb = nullptr;
-            if (o.pre) {
-                if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, (1 << cut) + 1, 0}; ce = sl.coarse->lv[cut].u; }
-                else { cs = slab_of(d, sl.plan.L(o.level - 1)); ce = buf(sl, o.level - 1).u; }
-            }
-            if (o.post == 1) {
-                if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, sl.plan.c_rows, sl.plan.c_row0}; cb = sl.c_own; }
-                else { cs = slab_of(d, sl.plan.L(o.level - 1)); cb = buf(sl, o.level - 1).b; }
-            }
-            int flag = 0;
             DistProf pr(d, sl, timed, MGX_PROF_SMOOTH_FINE, o.mu);
-            pr.launches(dist_block_launches(d, g.N, o.mu, o.post));
-            const int rc = mgx_slab_cycle(&fs, lb.u, lb.b, lb.tmp, o.row_lo, o.row_hi, o.mu, d->cfg.omega, d->cfg.smoother,
-                                          (o.pre || o.post == 1) ? &cs : nullptr, ce, cb, o.crow_lo, o.crow_hi, d->cfg.restrict_mode,
-                                          o.post == 2 ? sl.scratch : nullptr, o.post == 2 ? sl.sum_dev : nullptr, &flag, (void*)sl.st);
-            if (rc != MGX_OK) return s->fail(rc, "mgx_slab_cycle failed on a slab");
-            if (flag) std::swap(lb.u, lb.tmp);
+            pr.launches(dist_block_launches(d, sl.plan.L(o.level).N, o.mu, o.post));
+            int flag = 0;
+            const int rc = dist_cycle_rows(s, d, sl, o, o.row_lo, o.row_hi, sl.st, &flag);
+            if (rc != MGX_OK) return rc;
+            if (flag) std::swap(buf(sl, o.level).u, buf(sl, o.level).tmp);
             return MGX_OK;
         }
         case MGX_DOP_SMOOTH: {
@@ -526,7 +602,53 @@ int dist_run(mgx_solver* s, mgx_dist* d, double* norm_out)
         const mgx_dist_op& o = d->slabs[0].ops[i];
         int rc = MGX_OK;
         switch (o.op) {
-            case MGX_DOP_EXCHANGE: rc = dist_exchange(s, d, o); break;
+            case MGX_DOP_EXCHANGE: {
+                auto none_after = [](DistSlab&, hipStream_t) { return (int)MGX_OK; };
+                auto none_meanwhile = [](DistSlab&) { return (int)MGX_OK; };
+                const int j = d->overlap ? dist_overlap_candidate(d, d->slabs[0], i) : -1;
+                bool fits = j > 0;
+                for (auto& sl : d->slabs) {
+                    int a, b;
+                    fits = fits && dist_overlap_candidate(d, sl, i) == j && dist_interior_rows(d, sl, sl.ops[j], &a, &b);
+                }
+                if (!fits) { rc = dist_exchange(s, d, o, false, none_after, none_meanwhile); break; }
+                // operations between the exchange and the pass (zero fills of coarser guesses) first
+                for (size_t k = i + 1; k < (size_t)j && rc == MGX_OK; ++k)
+                    for (auto& sl : d->slabs)
+                        if ((rc = dist_local_op(s, d, sl, sl.ops[k])) != MGX_OK) break;
+                if (rc != MGX_OK) break;
+                const bool timed = d->cfg.profile && d->slabs[0].ops[j].level == Lf;
+                std::vector<int> flags(d->slabs.size(), 0);
+                {
+                    DistProf pr(d, d->slabs[0], timed, MGX_PROF_SMOOTH_FINE, d->slabs[0].ops[j].mu);
+                    pr.launches(1);
+                    auto bands = [&](DistSlab& sl, hipStream_t xst) {
+                        const mgx_dist_op& c = sl.ops[j];
+                        int a, b, f = 0, r = MGX_OK;
+                        (void)dist_interior_rows(d, sl, c, &a, &b);
+                        if (a > c.row_lo) r = dist_cycle_rows(s, d, sl, c, c.row_lo, a, xst, &f);
+                        if (r == MGX_OK && b < c.row_hi) r = dist_cycle_rows(s, d, sl, c, b, c.row_hi, xst, &f);
+                        return r;
+                    };
+                    auto interior = [&](DistSlab& sl) {
+                        const mgx_dist_op& c = sl.ops[j];
+                        int a, b;
+                        (void)dist_interior_rows(d, sl, c, &a, &b);
+                        return dist_cycle_rows(s, d, sl, c, a, b, sl.st, &flags[&sl - &d->slabs[0]]);
+                    };
+                    rc = dist_exchange(s, d, o, true, bands, interior);
+                }
+                if (rc != MGX_OK) break;
+                for (auto& sl : d->slabs)
+                    if (flags[&sl - &d->slabs[0]]) std::swap(buf(sl, sl.ops[j].level).u, buf(sl, sl.ops[j].level).tmp);
+                if (d->slabs[0].ops[j].level == Lf) {
+                    const double n = (double)((1 << Lf) - 1);
+                    d->fine_updates += (double)d->slabs[0].ops[j].mu * n * n;
+                }
+                d->overlapped += 1;
+                i = (size_t)j;                               // the pass is done
+                break;
+            }
             case MGX_DOP_GATHER_CUT: rc = dist_gather_cut(s, d); break;
             case MGX_DOP_ALLREDUCE_NORM: {
                 double sum = 0.0;

@@ -86,6 +86,30 @@ def test_n_gpus_on_one_device_equal_the_single_gpu_solve(pkg, po, monkeypatch, P
         assert np.all(np.abs(np.array(h) - h_orc) <= 1e-10 * h_orc + 1e-13 * h_orc[0])
 
 
+@pytest.mark.parametrize("P,smoother,mu,dtype", [(2, "jacobi", 10, "f64"), (4, "jacobi", 10, "f64"), (8, "jacobi", 4, "f64"),
+                                                   (4, "rbgs", 2, "f64"), (2, "jacobi", 5, "f32")])
+def test_exchange_overlapped_with_the_interior_rows_changes_no_bit(pkg, po, monkeypatch, P, smoother, mu, dtype):
+    """a halo exchange followed by a one-pass pre-smoothing block runs on the slab's second stream while the
+    compute stream smooths the rows that need no halo; the edge bands follow the halos (three launches of
+    the same kernel on disjoint rows): same bits as the synchronous order and as one GPU"""
+    c = dict(finest=11, coarsest=6, mu1=mu, mu2=mu, smoother=smoother, dtype=dtype)
+    b, u0 = _problem(po, c)
+    h_ref, u_ref = _single(pkg, c, b, u0, 3)
+    out = {}
+    for ov in ("0", "1"):
+        monkeypatch.setenv("MGX_DIST_OVERLAP", ov)
+        with pkg.Multigrid(n_gpus=P, devices=[0] * P, cut_level=8, **_cfg(pkg, c)) as mg:
+            mg.set_rhs(b)
+            mg.set_guess(u0)
+            st, h = mg.solve(tol=0.0, max_cycles=3)
+            out[ov] = (mg.get_solution(), h, mg.exchanges(), mg.overlapped())
+    assert out["0"][3] == 0 and out["1"][3] > 0                       # it really overlapped
+    assert out["1"][3] <= out["1"][2] == out["0"][2]
+    for ov in ("0", "1"):
+        assert np.array_equal(out[ov][0], u_ref), ov
+        assert np.allclose(out[ov][1], h_ref, rtol=1e-13, atol=0)
+
+
 def test_multi_gpu_handle_device_fills_and_unsupported_calls(pkg):
     """inputs generated on the device (what bench.py does) equal the single-GPU fills; operator
     entry points that make no sense on a slab handle say so"""
