@@ -74,7 +74,7 @@ typedef struct {
      * processes of mgx_create_rank), levels <= cut_level solved redundantly per device
      * ("the bottom solve stays on one GPU").  Several slabs may share a device (devices[g] all 0
      * runs the whole slab plan on one GPU: how the 1-GPU tests check n_gpus = 2, 4, 8 bit for bit
-     * against n_gpus = 1).  Multi-GPU handles run V-cycles (schedule V), dtype F64 or F32. */
+     * against n_gpus = 1).  Multi-GPU handles: dtype F64 or F32, both schedules. */
     int n_gpus;           /* 0 or 1: single GPU */
     int cut_level;        /* 0: chosen from the grid and n_gpus */
     int devices[MGX_MAX_GPUS];   /* -1 entries: slab g on device g modulo the device count */
@@ -293,8 +293,8 @@ MGX_API long mgx_slab_scratch_doubles(const mgx_slab* s);
  * ncclUniqueId of rank 0 (mgx_rccl_unique_id) handed to every rank by the launcher.
  * On such handles: mgx_set_rhs / mgx_set_guess / mgx_get_solution (whole-grid host vectors; each
  * slab takes / returns its rows), mgx_fill_rhs, mgx_fill_guess_random, mgx_residual_norm (finest
- * level), mgx_vcycle (finest level), mgx_solve, mgx_synchronize, mgx_destroy; everything else
- * returns MGX_ERR_STATE.
+ * level), mgx_vcycle (finest level), mgx_fmg, mgx_solve, mgx_synchronize, mgx_destroy; everything
+ * else returns MGX_ERR_STATE.
  * ===========================================================================*/
 enum {
     MGX_DOP_EXCHANGE = 1,       /* fill `depth` halo rows of `which` (U / B) of `level` from both neighbours */
@@ -306,7 +306,11 @@ enum {
     MGX_DOP_GATHER_CUT = 7,     /* all-gather the slabs' shares of the cut level's right-hand side */
     MGX_DOP_COARSE = 8,         /* one V-cycle from e = 0 on levels cut..coarsest (replicated) */
     MGX_DOP_SUMSQ = 9,          /* sum of (b - A u)^2 over rows [row_lo,row_hi) of the finest level */
-    MGX_DOP_ALLREDUCE_NORM = 10 /* sum the slabs' sums of squares; the norm is its square root */
+    MGX_DOP_ALLREDUCE_NORM = 10,/* sum the slabs' sums of squares; the norm is its square root */
+    /* fullmultigrid on slabs (PS:629-650) */
+    MGX_DOP_RESTRICT_RHS = 11,  /* B[level-1] = R B[level] (PS:641), coarse rows [crow_lo,crow_hi) */
+    MGX_DOP_PROLONG_SET = 12,   /* U[level] = P U[level-1] (PS:645) on fine rows [row_lo,row_hi) */
+    MGX_DOP_COARSE_FMG = 13     /* fullmultigrid on levels cut..coarsest from the gathered right-hand side (replicated) */
 };
 typedef struct {
     int op, level;
@@ -340,6 +344,9 @@ MGX_API int mgx_plan_guess_set(mgx_plan_handle p, int all_rows);
 /* operations of one V-cycle / of the residual norm, in order; returns the count (< 0: cap too small) */
 MGX_API int mgx_plan_vcycle(mgx_plan_handle p, mgx_dist_op* ops, int cap);
 MGX_API int mgx_plan_norm(mgx_plan_handle p, mgx_dist_op* ops, int cap);
+/* operations of fullmultigrid (PS:629-650): right-hand sides restricted down to the cut level, FMG on
+ * the replicated levels, then per slab level prolongation + mu0 + 1 V-cycles */
+MGX_API int mgx_plan_fmg(mgx_plan_handle p, mgx_dist_op* ops, int cap);
 
 /* what moves between slabs of different processes */
 typedef struct { int send; int peer; void* ptr; size_t bytes; } mgx_xfer;   /* send = 1: ptr -> peer; 0: peer -> ptr */

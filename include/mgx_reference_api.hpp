@@ -115,7 +115,6 @@ inline std::vector<matrix_elements_for_jacobi>& build_hierarchy(const parameters
     cfg.device = prm.device;
     cfg.n_gpus = prm.n_gpus;
     for (int i = 0; i < MGX_MAX_GPUS; ++i) cfg.devices[i] = prm.devices[i];
-    if (prm.n_gpus > 1) cfg.schedule = MGX_SCHEDULE_V;        // multi-GPU handles run V-cycles
     check(mgx_create(&cfg, &H.handle), nullptr, "mgx_create");
     H.jacobi_matrices.assign(prm.finest_level - prm.coarsest_level + 1, {});
     for (int level = prm.coarsest_level; level <= prm.finest_level; ++level) {   // PS:661

@@ -39,12 +39,12 @@ EXPORTS = [
     "mgx_slab_jacobi", "mgx_slab_rbgs", "mgx_slab_restrict", "mgx_slab_prolong",
     "mgx_slab_residual_sumsq", "mgx_slab_scratch_doubles",
     "mgx_plan_create", "mgx_plan_destroy", "mgx_plan_last_error", "mgx_plan_cut_level", "mgx_plan_level",
-    "mgx_plan_cut_share", "mgx_plan_guess_set", "mgx_plan_vcycle", "mgx_plan_norm", "mgx_rccl_unique_id",
+    "mgx_plan_cut_share", "mgx_plan_guess_set", "mgx_plan_vcycle", "mgx_plan_norm", "mgx_plan_fmg", "mgx_rccl_unique_id",
     "mgx_create_rank", "mgx_dist_exchanges", "mgx_dist_overlapped", "mgx_memcpy_d2h", "mgx_memcpy_h2d",
 ]
 MAX_GPUS = 16
 (DOP_EXCHANGE, DOP_ZERO_U, DOP_CYCLE, DOP_SMOOTH, DOP_RESTRICT, DOP_PROLONG, DOP_GATHER_CUT, DOP_COARSE, DOP_SUMSQ,
- DOP_ALLREDUCE_NORM) = range(1, 11)
+ DOP_ALLREDUCE_NORM, DOP_RESTRICT_RHS, DOP_PROLONG_SET, DOP_COARSE_FMG) = range(1, 14)
 
 
 class Config(C.Structure):
@@ -176,6 +176,7 @@ def lib() -> C.CDLL:
     L.mgx_plan_guess_set.argtypes = [vp, C.c_int]
     L.mgx_plan_vcycle.argtypes = [vp, C.POINTER(DistOp), C.c_int]
     L.mgx_plan_norm.argtypes = [vp, C.POINTER(DistOp), C.c_int]
+    L.mgx_plan_fmg.argtypes = [vp, C.POINTER(DistOp), C.c_int]
     L.mgx_rccl_unique_id.argtypes = [vp]
     L.mgx_create_rank.argtypes = [C.POINTER(Config), C.c_int, C.c_int, vp, C.POINTER(Transport), C.POINTER(vp)]
     L.mgx_dist_exchanges.argtypes = [vp]
@@ -232,11 +233,15 @@ class Plan:
         lib().mgx_plan_guess_set(self._h, 1 if all_rows else 0)
 
     def _emit(self, fn):
-        buf = (DistOp * 256)()
-        n = fn(self._h, buf, 256)
+        cap = 4096
+        buf = (DistOp * cap)()
+        n = fn(self._h, buf, cap)
         if n < 0:
-            raise MgxError("plan longer than 256 operations")
+            raise MgxError(f"plan longer than {cap} operations")
         return [buf[i] for i in range(n)]
+
+    def fmg(self):
+        return self._emit(lib().mgx_plan_fmg)
 
     def vcycle(self):
         return self._emit(lib().mgx_plan_vcycle)

@@ -1158,7 +1158,10 @@ int mgx_vcycle_zero(mgx_handle s)
 int mgx_fmg(mgx_handle s)
 {
     if (!s) return MGX_ERR_INVALID;
-    NO_DIST(s)
+    if (s->dist) {
+        int rc = dist_fmg(s, s->dist);
+        return rc ? rc : dist_sync(s, s->dist);
+    }
     MIXED_GUARD(s->cfg.finest_level)
     int rc = fmg(s);
     if (rc) return rc;
@@ -1588,7 +1591,6 @@ int mgx_create_rank(const mgx_config* cfg, int rank, int world, const void* rccl
     mgx_solver* s = new (std::nothrow) mgx_solver();
     if (!s) { g_create_error = "out of host memory"; return MGX_ERR_ALLOC; }
     s->cfg = *cfg;
-    s->cfg.schedule = MGX_SCHEDULE_V;          // multi-GPU handles run V-cycles (mgx.h)
     const int rc = dist_create(s, &s->cfg, rank, world, rccl_id, transport);
     if (rc != MGX_OK) { g_create_error = s->err; mgx_destroy(s); return rc; }
     *out = s;
@@ -1677,5 +1679,16 @@ static int plan_emit(mgx_plan_handle p, mgx_dist_op* ops, int cap, bool norm)
 }
 int mgx_plan_vcycle(mgx_plan_handle p, mgx_dist_op* ops, int cap) { return plan_emit(p, ops, cap, false); }
 int mgx_plan_norm(mgx_plan_handle p, mgx_dist_op* ops, int cap) { return plan_emit(p, ops, cap, true); }
+int mgx_plan_fmg(mgx_plan_handle p, mgx_dist_op* ops, int cap)
+{
+    if (!p || (!ops && cap > 0)) return MGX_ERR_INVALID;
+    std::vector<mgx_dist_op> v;
+    mgx::DistPlanner trial = p->p;
+    trial.emit_fmg(v);
+    if ((int)v.size() > cap) return -(int)v.size();
+    p->p = trial;
+    for (size_t i = 0; i < v.size(); ++i) ops[i] = v[i];
+    return (int)v.size();
+}
 
 } // extern "C"

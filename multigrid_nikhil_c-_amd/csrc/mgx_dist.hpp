@@ -87,7 +87,7 @@ DistPlanCfg plan_cfg_of(const mgx_config& c, int P, int g, int cut, bool fold, b
 {
     DistPlanCfg pc;
     pc.finest = c.finest_level; pc.cut = cut; pc.coarsest = std::min(c.coarsest_level, cut);
-    pc.mu1 = c.mu1; pc.mu2 = c.mu2; pc.smoother = c.smoother; pc.P = P; pc.g = g; pc.fold = fold; pc.deep = deep;
+    pc.mu0 = c.mu0; pc.mu1 = c.mu1; pc.mu2 = c.mu2; pc.smoother = c.smoother; pc.P = P; pc.g = g; pc.fold = fold; pc.deep = deep;
     return pc;
 }
 
@@ -559,6 +559,19 @@ int dist_local_op(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op& o
             if (rc != MGX_OK) return s->fail(rc, "mgx_slab_restrict failed on a slab");
             return MGX_OK;
         }
+        case MGX_DOP_RESTRICT_RHS: {
+            const mgx_dist_level& g = sl.plan.L(o.level);
+            DistLevelBuf& lb = buf(sl, o.level);
+            const mgx_slab fs = slab_of(d, g);
+            mgx_slab cs;
+            void* cb;
+            if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, sl.plan.c_rows, sl.plan.c_row0}; cb = sl.c_own; }
+            else { cs = slab_of(d, sl.plan.L(o.level - 1)); cb = buf(sl, o.level - 1).b; }
+            const int rc = mgx_slab_restrict(&fs, nullptr, lb.b, &cs, cb, nullptr, o.crow_lo, o.crow_hi, d->cfg.restrict_mode, 0, (void*)sl.st);
+            if (rc != MGX_OK) return s->fail(rc, "mgx_slab_restrict (right-hand side) failed on a slab");
+            return MGX_OK;
+        }
+        case MGX_DOP_PROLONG_SET:
         case MGX_DOP_PROLONG: {
             const mgx_dist_level& g = sl.plan.L(o.level);
             DistLevelBuf& lb = buf(sl, o.level);
@@ -567,7 +580,7 @@ int dist_local_op(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op& o
             const void* ce;
             if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, (1 << cut) + 1, 0}; ce = sl.coarse->lv[cut].u; }
             else { cs = slab_of(d, sl.plan.L(o.level - 1)); ce = buf(sl, o.level - 1).u; }
-            const int rc = mgx_slab_prolong(&fs, lb.u, &cs, ce, o.row_lo, o.row_hi, 1, (void*)sl.st);
+            const int rc = mgx_slab_prolong(&fs, lb.u, &cs, ce, o.row_lo, o.row_hi, o.op == MGX_DOP_PROLONG ? 1 : 0, (void*)sl.st);
             if (rc != MGX_OK) return s->fail(rc, "mgx_slab_prolong failed on a slab");
             return MGX_OK;
         }
@@ -576,6 +589,12 @@ int dist_local_op(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op& o
             double unused = 0.0;
             const int rc = cycle_body(sl.coarse, false, true, &unused);
             if (rc != MGX_OK) return s->fail(rc, std::string("coarse V-cycle: ") + sl.coarse->err);
+            return MGX_OK;
+        }
+        case MGX_DOP_COARSE_FMG: {
+            // PS:629-650 on levels cut..coarsest (the gathered right-hand side is the handle's level-cut B)
+            const int rc = fmg(sl.coarse);
+            if (rc != MGX_OK) return s->fail(rc, std::string("coarse fullmultigrid: ") + sl.coarse->err);
             return MGX_OK;
         }
         case MGX_DOP_SUMSQ: {
@@ -685,6 +704,12 @@ int dist_run(mgx_solver* s, mgx_dist* d, double* norm_out)
 int dist_vcycle(mgx_solver* s, mgx_dist* d)
 {
     for (auto& sl : d->slabs) { sl.ops.clear(); sl.plan.emit_vcycle(sl.ops); }
+    return dist_run(s, d, nullptr);
+}
+
+int dist_fmg(mgx_solver* s, mgx_dist* d)
+{
+    for (auto& sl : d->slabs) { sl.ops.clear(); sl.plan.emit_fmg(sl.ops); }
     return dist_run(s, d, nullptr);
 }
 
@@ -811,7 +836,8 @@ int dist_solve(mgx_solver* s, mgx_dist* d, double tol, int max_cycles, mgx_stats
     int k = 0;
     for (; k < max_cycles; ++k) {
         if (hist[k] <= tol * hist[0]) break;
-        if ((rc = dist_vcycle(s, d))) return rc;
+        if (k == 0 && d->cfg.schedule == MGX_SCHEDULE_FMG) { if ((rc = dist_fmg(s, d))) return rc; }   // PS:727
+        else if ((rc = dist_vcycle(s, d))) return rc;
         if ((rc = dist_norm(s, d, &r))) return rc;
         hist.push_back(r);
     }

@@ -37,7 +37,7 @@ namespace mgx {
 
 struct DistPlanCfg {
     int finest = 0, cut = 0, coarsest = 0;
-    int mu1 = 0, mu2 = 0;
+    int mu0 = 0, mu1 = 0, mu2 = 0;
     int smoother = MGX_SMOOTHER_JACOBI;
     int P = 1, g = 0;          // number of slabs, this slab
     bool fold = true;          // transfers folded into the smoother passes (mgx_slab_cycle)
@@ -182,6 +182,41 @@ public:
             out.push_back(o);
             if (c.mu2 > 0) smooth(out, l, c.mu2, k_post);                                           // PS:625
             else uh(l) = std::min(uh(l), k_post);
+        }
+    }
+
+    // ---- fullmultigrid (PS:629-650) on the slab hierarchy ------------------------------------------
+    // PS:641: the right-hand side of every coarser level is the restriction of the finer one; the levels
+    // <= cut run fullmultigrid themselves on the gathered right-hand side (replicated); then, level by
+    // level, the interpolated solution (PS:645) and mu0 + 1 V-cycles (PS:646-648).  The finest
+    // right-hand side must hold the global field on every row of the slab, halos included.
+    void emit_fmg(std::vector<mgx_dist_op>& out)
+    {
+        sumsq_ready = false;
+        for (int l = c.finest; l > c.cut; --l) {
+            mgx_dist_level& Lv = L(l);
+            const int NC = Lv.N / 2;
+            const int glo = std::max(c.g * (NC / c.P), 1), ghi = std::min((c.g + 1) * (NC / c.P), NC);
+            const bool to_cut = !(l - 1 > c.cut);
+            const int crow0 = to_cut ? c_row0 : L(l - 1).row0;
+            mgx_dist_op o = op(MGX_DOP_RESTRICT_RHS, l);                       // PS:641
+            o.coarse_is_cut = to_cut ? 1 : 0;
+            o.crow_lo = glo - crow0; o.crow_hi = ghi - crow0;
+            out.push_back(o);
+            if (!to_cut) exchange(out, l - 1, MGX_VEC_B, L(l - 1).halo);        // its restriction and its V-cycles read the halos
+        }
+        out.push_back(op(MGX_DOP_GATHER_CUT, c.cut));
+        out.push_back(op(MGX_DOP_COARSE_FMG, c.cut));
+        for (int l = c.cut + 1; l <= c.finest; ++l) {
+            mgx_dist_level& Lv = L(l);
+            const bool to_cut = !(l - 1 > c.cut);
+            if (!to_cut && uh(l - 1) < 1) { exchange(out, l - 1, MGX_VEC_U, L(l - 1).halo); uh(l - 1) = L(l - 1).halo; }
+            mgx_dist_op o = op(MGX_DOP_PROLONG_SET, l);                         // PS:645
+            o.row_lo = upd_lo(Lv); o.row_hi = upd_hi(Lv);
+            o.coarse_is_cut = to_cut ? 1 : 0;
+            out.push_back(o);
+            uh(l) = 0;                                                          // owned rows only: the first V-cycle exchanges
+            for (int i = 0; i <= c.mu0; ++i) emit_vcycle(out, l);               // PS:646-648
         }
     }
 

@@ -146,7 +146,7 @@ class OracleCoarseSolver:
 
     def __init__(self, po, cut_level, coarsest_level, cfg):
         self.level = cut_level
-        self.s = po.Solver(finest_level=cut_level, coarsest_level=coarsest_level, mu1=cfg["mu1"], mu2=cfg["mu2"],
+        self.s = po.Solver(finest_level=cut_level, coarsest_level=coarsest_level, mu0=cfg.get("mu0", 0), mu1=cfg["mu1"], mu2=cfg["mu2"],
                            omega=cfg["omega"], smoother=1 if cfg["smoother"] == "rbgs" else 0, schedule=0,
                            restrict_mode=cfg["restrict_mode"], bottom=cfg["bottom"])
 
@@ -154,5 +154,13 @@ class OracleCoarseSolver:
         N = 1 << self.level
         b = np.ascontiguousarray(b_full.numpy()[1:N, 1:N].astype(np.float64))
         e = self.s.vcycle(self.level, np.zeros_like(b), b)
+        e_full.zero_()
+        e_full.numpy()[1:N, 1:N] = e
+
+    def fmg(self, b_full, e_full):
+        """e_full <- fullmultigrid (PS:629-650) on levels cut..coarsest for the gathered right-hand side"""
+        N = 1 << self.level
+        b = np.ascontiguousarray(b_full.numpy()[1:N, 1:N].astype(np.float64))
+        e = self.s.fmg(self.level, b)
         e_full.zero_()
         e_full.numpy()[1:N, 1:N] = e

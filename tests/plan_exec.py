@@ -96,10 +96,16 @@ class PlanRunner:
                 g = self.geom[l]
                 r0, cb = self._coarse(o, "b")
                 self.ops.restrict(l, g.row0, self.u[l], self.b[l], r0, cb, None, o.crow_lo, o.crow_hi, cfg["restrict_mode"], fused=True)
-            elif o.op == pkg.binding.DOP_PROLONG:
+            elif o.op in (pkg.binding.DOP_PROLONG, pkg.binding.DOP_PROLONG_SET):
                 g = self.geom[l]
                 r0, e = self._coarse(o, "e")
-                self.ops.prolong(l, g.row0, self.u[l], r0, e, o.row_lo, o.row_hi, add=True)
+                self.ops.prolong(l, g.row0, self.u[l], r0, e, o.row_lo, o.row_hi, add=(o.op == pkg.binding.DOP_PROLONG))
+            elif o.op == pkg.binding.DOP_RESTRICT_RHS:
+                g = self.geom[l]
+                r0, cb = self._coarse(o, "b")
+                self.ops.restrict(l, g.row0, None, self.b[l], r0, cb, None, o.crow_lo, o.crow_hi, cfg["restrict_mode"], fused=False)
+            elif o.op == pkg.binding.DOP_COARSE_FMG:
+                self.coarse.fmg(self.c_b, self.c_e)
             elif o.op == pkg.binding.DOP_GATHER_CUT:
                 NC = 1 << self.cut
                 if self.P > 1:
@@ -121,11 +127,11 @@ class PlanRunner:
                 raise ValueError(f"unknown plan operation {o.op}")
         return norm
 
-    def solve(self, tol=1e-8, max_cycles=50):
+    def solve(self, tol=1e-8, max_cycles=50, fmg=False):
         hist = [self.run(self.plan.norm())]
         k = 0
         while k < max_cycles and not (hist[k] <= tol * hist[0]):
-            self.run(self.plan.vcycle())
+            self.run(self.plan.fmg() if (fmg and k == 0) else self.plan.vcycle())
             hist.append(self.run(self.plan.norm()))
             k += 1
         return k, hist

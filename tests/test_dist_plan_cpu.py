@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _mgx_cfg(cfg):
-    return dict(finest_level=cfg["finest"], coarsest_level=cfg["coarsest"], cut_level=cfg["cut"], mu1=cfg["mu1"], mu2=cfg["mu2"],
+    return dict(finest_level=cfg["finest"], coarsest_level=cfg["coarsest"], cut_level=cfg["cut"], mu0=cfg.get("mu0", 0), mu1=cfg["mu1"], mu2=cfg["mu2"],
                 omega=cfg["omega"], smoother=1 if cfg["smoother"] == "rbgs" else 0, restrict_mode=cfg["restrict_mode"],
                 bottom=cfg["bottom"], schedule=0)
 
@@ -44,8 +44,11 @@ def _worker(rank, world, port, cfg, ret):
         L = cfg["finest"]
         n = (1 << L) - 1
         mg.set_fine("b", np.pad(po.rhs_sine(L), 1))
-        mg.set_fine("u", np.pad(po.fill_uniform((n, n), 12345), 1))
-        k, hist = mg.solve(tol=1e-8, max_cycles=cfg["max_cycles"])
+        if cfg.get("fmg"):
+            mg.set_fine("u", np.zeros((n + 2, n + 2)))
+        else:
+            mg.set_fine("u", np.pad(po.fill_uniform((n, n), 12345), 1))
+        k, hist = mg.solve(tol=1e-8, max_cycles=cfg["max_cycles"], fmg=bool(cfg.get("fmg")))
         if rank == 0:
             ret["hist"] = hist
         ret[f"rows{rank}"] = mg.own_interior()
@@ -65,10 +68,11 @@ def _run(world, cfg):
 def _reference(po, cfg):
     L = cfg["finest"]
     n = (1 << L) - 1
-    s = po.Solver(finest_level=L, coarsest_level=cfg["coarsest"], mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"],
-                  smoother=1 if cfg["smoother"] == "rbgs" else 0, schedule=0, restrict_mode=cfg["restrict_mode"],
-                  bottom=cfg["bottom"])
-    return s.solve(po.rhs_sine(L), po.fill_uniform((n, n), 12345), tol=1e-8, max_cycles=cfg["max_cycles"])
+    s = po.Solver(finest_level=L, coarsest_level=cfg["coarsest"], mu0=cfg.get("mu0", 0), mu1=cfg["mu1"], mu2=cfg["mu2"], omega=cfg["omega"],
+                  smoother=1 if cfg["smoother"] == "rbgs" else 0, schedule=1 if cfg.get("fmg") else 0,
+                  restrict_mode=cfg["restrict_mode"], bottom=cfg["bottom"])
+    u0 = None if cfg.get("fmg") else po.fill_uniform((n, n), 12345)
+    return s.solve(po.rhs_sine(L), u0, tol=1e-8, max_cycles=cfg["max_cycles"])
 
 
 BASE = dict(finest=8, cut=6, coarsest=4, mu1=2, mu2=1, omega=2.0 / 3.0, smoother="jacobi", restrict_mode=0, bottom=0,
@@ -130,6 +134,23 @@ def test_eight_ranks_three_distributed_levels(po):
         assert np.max(np.abs(own - u_ref[lo - 1:hi - 1])) <= 1e-12 * np.max(np.abs(u_ref))
     assert rows == (1 << 10) - 1                       # the slabs tile the unknown rows exactly
     assert got["exch0"] <= (len(h) - 1) * (1 + 2) + 2, got["exch0"]
+
+
+@pytest.mark.parametrize("world,mu0,smoother,fold", [(2, 0, "jacobi", True), (4, 1, "jacobi", True), (2, 1, "rbgs", True),
+                                                    (2, 0, "jacobi", False)])
+def test_fullmultigrid_on_slabs_matches_the_oracle(po, world, mu0, smoother, fold):
+    """PS:629-650 through the slab plan (mgx_plan_fmg): right-hand sides restricted level by level with
+    their halos exchanged, fullmultigrid on the replicated levels, prolongation + mu0 + 1 V-cycles per
+    slab level; then V-cycles to the tolerance - the oracle's FMG solve"""
+    cfg = dict(BASE, finest=9, cut=6, coarsest=4, mu0=mu0, mu1=2, mu2=1, smoother=smoother, fold=fold, fmg=True, max_cycles=5)
+    got = _run(world, cfg)
+    u_ref, h_ref = _reference(po, cfg)
+    h = np.array(got["hist"])
+    assert len(h) == len(h_ref)
+    assert np.all(np.abs(h - h_ref) <= 1e-10 * h_ref + 1e-13 * h_ref[0]), (h, h_ref)
+    for r in range(world):
+        lo, hi, own = got[f"rows{r}"]
+        assert np.max(np.abs(own - u_ref[lo - 1:hi - 1])) <= 1e-12 * np.max(np.abs(u_ref))
 
 
 def test_plan_geometry_and_defaults(pkg):

@@ -110,6 +110,40 @@ def test_exchange_overlapped_with_the_interior_rows_changes_no_bit(pkg, po, monk
         assert np.allclose(out[ov][1], h_ref, rtol=1e-13, atol=0)
 
 
+@pytest.mark.parametrize("P,smoother,mu0,mu1,mu2,fold,deep,dtype", [(2, "jacobi", 0, 2, 1, True, True, "f64"),
+                                                                      (4, "jacobi", 1, 10, 10, True, True, "f64"),
+                                                                      (2, "rbgs", 1, 2, 1, True, True, "f64"),
+                                                                      (2, "jacobi", 0, 3, 2, False, False, "f64"),
+                                                                      (8, "jacobi", 0, 2, 2, True, True, "f32")])
+def test_fullmultigrid_on_slabs_equals_the_single_gpu_schedule(pkg, po, monkeypatch, P, smoother, mu0, mu1, mu2, fold, deep, dtype):
+    """PS:629-650 on a multi-GPU handle (mgx_plan_fmg's operation list run by the executor): the FMG pass
+    alone (mgx_fmg) and the FMG-started solve are bit for bit the single-GPU ones"""
+    c = dict(finest=10, coarsest=5, mu1=mu1, mu2=mu2, smoother=smoother, dtype=dtype)
+    monkeypatch.setenv("MGX_DIST_FOLD", "1" if fold else "0")
+    monkeypatch.setenv("MGX_DIST_DEEP", "1" if deep else "0")
+    b, _ = _problem(po, c)
+    kw = dict(_cfg(pkg, c), schedule=1, mu0=mu0)
+    with pkg.Multigrid(**kw) as one, pkg.Multigrid(n_gpus=P, devices=[0] * P, cut_level=7, **kw) as many:
+        res = {}
+        for name, mg in (("one", one), ("many", many)):
+            u_fmg = mg.fullmultigrid(b)
+            r_fmg = mg.residual_norm()
+            mg.set_rhs(b)
+            mg.zero_level(10, pkg.VEC_U)
+            st, h = mg.solve(tol=1e-9, max_cycles=20)
+            res[name] = (u_fmg, r_fmg, mg.get_solution(), h, st.cycles)
+    assert np.array_equal(res["many"][0], res["one"][0])
+    assert res["many"][1] == pytest.approx(res["one"][1], rel=1e-13)
+    assert np.array_equal(res["many"][2], res["one"][2])
+    assert res["many"][4] == res["one"][4] and np.allclose(res["many"][3], res["one"][3], rtol=1e-13, atol=0)
+    assert res["one"][3][1] < 0.05 * res["one"][3][0]                  # the FMG pass did most of the work
+    if dtype == "f64":
+        _, h_orc = po.Solver(finest_level=10, coarsest_level=5, mu0=mu0, mu1=mu1, mu2=mu2, smoother=1 if smoother == "rbgs" else 0,
+                             schedule=1).solve(b, None, tol=1e-9, max_cycles=20)
+        h = np.array(res["many"][3])
+        assert len(h) == len(h_orc) and np.all(np.abs(h - h_orc) <= 1e-10 * h_orc + 1e-13 * h_orc[0])
+
+
 def test_multi_gpu_handle_device_fills_and_unsupported_calls(pkg):
     """inputs generated on the device (what bench.py does) equal the single-GPU fills; operator
     entry points that make no sense on a slab handle say so"""
@@ -221,6 +255,7 @@ def test_poisson_driver_binary_runs_the_reference_sequence(pkg):
     assert "Size of finest level solution is 4190209" in out4.stdout       # 2047^2
     assert "Program Running Correctly" in out4.stdout and "4 GPUs" in out4.stdout
     assert "u(1/2,1/2) = 0.29468" in out4.stdout
+    assert "fullmultigrid: " in out4.stdout                                   # PS:727 on the slabs too
 
 
 def test_config4_grid_on_eight_slabs_equals_the_single_gpu_solve(pkg):
