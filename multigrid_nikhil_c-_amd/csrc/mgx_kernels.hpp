@@ -138,13 +138,70 @@ __device__ __forceinline__ void bstore8(float2 v, __amdgpu_buffer_rsrc_t r, unsi
     const v2i32 t = {__float_as_int(v.x), __float_as_int(v.y)};
     __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, 0, 0);
 }
-// what an interior body needs to store without branches (built once per wave from uniform values)
+// ---- branch-free loads for the edge bodies --------------------------------------------------------
+// Waves whose dependency cone touches a boundary row or column, or the end of the rows that exist,
+// used to run a predicated body (a conditional load or store per predicate, one basic block each):
+// twice the instructions of the interior body and one row in flight, and since nothing else runs
+// once the interior waves are done, a pass ended with a tail as long as a whole chunk (small levels,
+// where every workgroup is resident at once, simply took as long as their slowest edge wave).  The
+// edge bodies are now the same straight-line code: their loads go through raw buffer descriptors as
+// well - a row or lane that must not be read gets the out-of-range offset and reads 0 - and the
+// Dirichlet rows and columns are re-zeroed with selects (+4 v_cndmask per level).
+__device__ __forceinline__ double2 bload(double2*, __amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    const v4i32 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_double2(__hiloint2double(t.y, t.x), __hiloint2double(t.w, t.z));
+}
+__device__ __forceinline__ float4 bload(float4*, __amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    const v4i32 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_float4(__int_as_float(t.x), __int_as_float(t.y), __int_as_float(t.z), __int_as_float(t.w));
+}
+__device__ __forceinline__ double bload1(double*, __amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    const v2i32 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+    return __hiloint2double(t.y, t.x);
+}
+__device__ __forceinline__ float bload1(float*, __amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+
+// What a body needs to load / store without branches (built once per wave from uniform values).
+// Every descriptor starts at the first row its wave can touch (rb fine, crb coarse) and offsets are
+// relative to it, so arrays of any size work with 32-bit offsets.
 struct FastOut {
     __amdgpu_buffer_rsrc_t out, cb, cz;    // fine output; coarse rhs and coarse guess (POST 1; cz empty when not wanted)
+    __amdgpu_buffer_rsrc_t in, rhs, ce;    // edge bodies: input iterate, right-hand side, coarse correction (PRE)
     unsigned lane_off;                     // byte offset of this lane's vector in a fine row
     unsigned clane_off;                    // byte offset of this lane's first coarse column in a coarse row
     unsigned pitch_bytes, cpitch_bytes;
+    int rb, crb;                           // the rows the descriptors start at
 };
+// bytes from row `first` to the end of row `last` of an array, as a descriptor range (a wave reaches
+// a few hundred rows beyond its first one: clamping keeps kOobOffset out of range)
+__device__ __forceinline__ unsigned rsrc_bytes(int first, int last, unsigned long row_bytes)
+{
+    if (last < first) return 0u;
+    const unsigned long b = (unsigned long)(last - first + 1) * row_bytes;
+    return b < 0x7FFFFF00ul ? (unsigned)b : 0x7FFFFF00u;
+}
+// column masks of a lane: its first column is the Dirichlet column 0 / its columns lie at or beyond column N
+struct ColMask { bool first, all; };
+__device__ __forceinline__ ColMask col_mask(long col, int N) { return ColMask{col == 0, col >= N}; }
+// zero the columns that are not unknowns, and everything when the row is not an unknown row (selects)
+__device__ __forceinline__ void mask_sel(double2& v, const ColMask& m, bool row_zero)
+{
+    v.x = (m.first || m.all || row_zero) ? 0.0 : v.x;
+    v.y = (m.all || row_zero) ? 0.0 : v.y;
+}
+__device__ __forceinline__ void mask_sel(float4& v, const ColMask& m, bool row_zero)
+{
+    v.x = (m.first || m.all || row_zero) ? 0.f : v.x;
+    v.y = (m.all || row_zero) ? 0.f : v.y;
+    v.z = (m.all || row_zero) ? 0.f : v.z;
+    v.w = (m.all || row_zero) ? 0.f : v.w;
+}
 
 // ---- wave -> (row chunk, column strip) --------------------------------------
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an XCD and its
@@ -156,7 +213,11 @@ struct Tile { int chunk, strip; bool active; };
 __device__ __forceinline__ Tile wave_tile(int strips, int chunks)
 {
     const int per_xcd = gridDim.x >> 3;
-    const int b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int xcd = blockIdx.x & 7;
+    // the upper four XCDs walk their ranges backwards: the last chunk row of the grid - boundary waves,
+    // which run the slower edge body - is then the first thing XCD 7 starts, not the last
+    const int nth = blockIdx.x >> 3;
+    const int b = xcd * per_xcd + (xcd >= 4 ? per_xcd - 1 - nth : nth);
     // the wave index as a scalar: everything derived from it (chunk, rows, row offsets, the
     // row predicates) then lives in SGPRs and costs no vector instruction
     const long g = (long)b * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -482,7 +543,7 @@ template <typename T, int K, bool EDGE, bool ZIN = false>
 __device__ __forceinline__ void
 fused_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
             const T* __restrict__ pv, const T* __restrict__ pb, long pitch, int r0, int r1, bool ld,
-            int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, bool zero_in)
+            int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, bool zero_in, const FastOut& fo)
 {
     using V = typename VecOf<T>::type;
     if constexpr (!EDGE) {
@@ -490,16 +551,16 @@ fused_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
         if constexpr (ZIN) in = vzero((V*)nullptr);
         else in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
         bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
-        return;
-    }
-    if (EDGE) {
+    } else {
+        // edge body: no branch either (see "branch-free loads" above).
         // [rd_lo, rd_hi]: rows inside the allocation and not beyond a boundary row;
         // zero_in: the input is known to be all zero (PS:613 coarse guess): do not read it
-        in = vload<V>(pv + (long)y * pitch, ld && !zero_in && y >= rd_lo && y <= rd_hi && y < r1 + K);
+        const bool in_ok = !zero_in && y >= rd_lo && y <= rd_hi && y < r1 + K;
         // rhs rows are needed only where some level is: [r0-K+1, r1+K-1)
-        bn = vload<V>(pb + (long)(y - 1) * pitch,
-                      ld && (y - 1) > bnd_lo && (y - 1) < bnd_hi && (y - 1) >= rd_lo && (y - 1) <= rd_hi &&
-                      y >= r0 - K + 2 && y < r1 + K);
+        const bool b_ok = (y - 1) > bnd_lo && (y - 1) < bnd_hi && (y - 1) >= rd_lo && (y - 1) <= rd_hi &&
+                          y >= r0 - K + 2 && y < r1 + K;
+        in = bload((V*)nullptr, fo.in, (ld && in_ok) ? (unsigned)(y - fo.rb) * fo.pitch_bytes + fo.lane_off : kOobOffset);
+        bn = bload((V*)nullptr, fo.rhs, (ld && b_ok) ? (unsigned)(y - 1 - fo.rb) * fo.pitch_bytes + fo.lane_off : kOobOffset);
     }
 }
 
@@ -525,7 +586,6 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
 {
     using V = typename VecOf<T>::type;
     constexpr int S_OLD = (P + 1) % 3, S_MID = (P + 2) % 3, S_NEW = P;
-    const V Z = vzero((V*)nullptr);
     // level 0: input row y and rhs row y-1 were loaded three steps ago into this phase's
     // prefetch slot (each rotation phase owns one slot, so the prefetch queue needs no
     // register moves either); refill the slot with the rows of step y+3 before computing.
@@ -534,7 +594,8 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
     const V in = nin[0], bn = nbn[0];
 #pragma unroll
     for (int q = 0; q + 1 < kPfStages; ++q) { nin[q] = nin[q + 1]; nbn[q] = nbn[q + 1]; }
-    fused_loads<T, K, EDGE, ZIN>(nin[kPfStages - 1], nbn[kPfStages - 1], y + kPrefetch, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
+    fused_loads<T, K, EDGE, ZIN>(nin[kPfStages - 1], nbn[kPfStages - 1], y + kPrefetch, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in, fo);
+    const ColMask cm = col_mask(col, N);
 #pragma unroll
     for (int j = K - 1; j > 0; --j) bw[j] = bw[j - 1];
     if constexpr (SM == 0) bw[0] = vscale(c1, bn);       // Jacobi: the window holds c1 * b (see jacobi_vec_pre)
@@ -547,17 +608,12 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
         V o;
         if constexpr (SM == 0) o = jacobi_vec_pre(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1);
         else o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1, par_c + row);
-        if (EDGE) {
-            mask_cols(o, col, N);
-            if (!(row > bnd_lo && row < bnd_hi)) o = Z;          // Dirichlet rows stay zero
-        }
+        if constexpr (EDGE) mask_sel(o, cm, !(row > bnd_lo && row < bnd_hi));     // Dirichlet rows and columns stay zero
         if (j < K) {
             lev[j][S_NEW] = o;
-        } else if constexpr (!EDGE) {
-            const unsigned at = (unsigned)row * fo.pitch_bytes + fo.lane_off;
-            bstore(o, fo.out, (st && row >= r0 && row < r1) ? at : kOobOffset);
         } else {
-            vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);
+            const unsigned at = (unsigned)(row - fo.rb) * fo.pitch_bytes + fo.lane_off;
+            bstore(o, fo.out, (st && row >= r0 && row < r1) ? at : kOobOffset);
         }
     }
 }
@@ -580,14 +636,14 @@ fused_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     // interior body the caller guarantees five more rows exist below the cone:
     // two for the rounding, three for the prefetch)
     const int y0 = r0 - K;
-    constexpr int kRound = EDGE ? 3 : trip_steps<T>();
+    constexpr int kRound = trip_steps<T>();
     const int steps = (r1 + K - y0 + kRound - 1) / kRound * kRound;
     V nin[3][kPfStages], nbn[3][kPfStages];        // [rotation phase][queue position]
 #pragma unroll
     for (int q = 0; q < kPrefetch; ++q)
-        fused_loads<T, K, EDGE, ZIN>(nin[q % 3][q / 3], nbn[q % 3][q / 3], y0 + q, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in);
+        fused_loads<T, K, EDGE, ZIN>(nin[q % 3][q / 3], nbn[q % 3][q / 3], y0 + q, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in, fo);
 #define MGX_FSTEP(P, Y) fused_step<T, K, SM, EDGE, P, ZIN>(lev, bw, nin[P], nbn[P], Y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in, fo)
-    if constexpr (!EDGE && trip_steps<T>() == 12) {
+    if constexpr (trip_steps<T>() == 12) {
         for (int y = y0; y < y0 + steps; y += 12) {
             MGX_FSTEP(0, y); MGX_FSTEP(1, y + 1); MGX_FSTEP(2, y + 2);
             MGX_FSTEP(0, y + 3); MGX_FSTEP(1, y + 4); MGX_FSTEP(2, y + 5);
@@ -633,16 +689,22 @@ k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     const bool interior = (vx0 >= 1) && ((long)(vx0 + kWave) * W < N) &&
                           (r0 - K - 1 > bnd_lo) && (r0 - K - 1 >= 0) &&
                           (r1 + K + trip_steps<T>() + kPrefetch < bnd_hi) && (r1 + K + trip_steps<T>() + kPrefetch <= rows_alloc - 1);
-    // the interior bodies store through 32-bit buffer offsets (local rows of this array)
-    const unsigned long out_bytes = (unsigned long)rows_alloc * (unsigned long)pitch * sizeof(T);
+    // both bodies store (and the edge body loads) through buffer descriptors that start at the first
+    // row this wave can touch, with 32-bit offsets relative to it
     FastOut fo;
-    fo.out = make_rsrc(vout, out_bytes < 0xFFFFF000ul ? (unsigned)out_bytes : 0u);
-    fo.cb = fo.out; fo.cz = fo.out;                  // unused here
-    fo.lane_off = (unsigned)(col * (long)sizeof(T));
-    fo.clane_off = 0;
+    fo.rb = max(r0 - K - 1, rd_lo);
+    fo.crb = 0;
     fo.pitch_bytes = (unsigned)(pitch * (long)sizeof(T));
     fo.cpitch_bytes = 0;
-    if (interior && out_bytes < 0xFFFFF000ul) {
+    const unsigned f_bytes = rsrc_bytes(fo.rb, rows_alloc - 1, fo.pitch_bytes);
+    const long f_at = (long)fo.rb * pitch;
+    fo.out = make_rsrc(vout + f_at, f_bytes);
+    fo.in = make_rsrc(vin + f_at, f_bytes);
+    fo.rhs = make_rsrc(rhs + f_at, f_bytes);
+    fo.cb = fo.out; fo.cz = fo.out; fo.ce = fo.out;   // unused here
+    fo.lane_off = (unsigned)(col * (long)sizeof(T));
+    fo.clane_off = 0;
+    if (interior) {
         if (zero_in) fused_body<T, K, SM, false, true>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, true, fo);
         else fused_body<T, K, SM, false, false>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, false, fo);
     } else {
@@ -963,19 +1025,27 @@ template <typename T, int CW> struct PreFetch { T a[CW + 1], b[CW + 1]; };
 template <typename T, bool EDGE>
 __device__ __forceinline__ void
 coarse_loads(PreFetch<T, VecOf<T>::W / 2>& pe, int y, const T* __restrict__ coarse_e, long cpitch, long ccol, int N, bool cld,
-             const CycleWin& win)
+             const CycleWin& win, const FastOut& fo)
 {
     constexpr int CW = VecOf<T>::W / 2;
     const int I = y >> 1;
-    const bool cl = EDGE ? (cld && y > 0 && y < N && I >= win.crow_first && I + (y & 1) <= win.crow_last) : true;
-    const T* p = coarse_e + (long)I * cpitch + ccol;
+    if constexpr (!EDGE) {
+        const T* p = coarse_e + (long)I * cpitch + ccol;
 #pragma unroll
-    for (int k = 0; k <= CW; ++k) pe.a[k] = cl ? p[k] : (T)0;
-    // the row below is only used by odd fine rows; loading it always keeps the step branch-free
-    const bool cl2 = EDGE ? (cl && (y & 1)) : true;
-    const T* q = p + cpitch;
+        for (int k = 0; k <= CW; ++k) pe.a[k] = p[k];
+        // the row below is only used by odd fine rows; loading it always keeps the step branch-free
+        const T* q = p + cpitch;
 #pragma unroll
-    for (int k = 0; k <= CW; ++k) pe.b[k] = cl2 ? q[k] : (T)0;
+        for (int k = 0; k <= CW; ++k) pe.b[k] = q[k];
+    } else {
+        const bool cl = cld && y > 0 && y < N && I >= win.crow_first && I + (y & 1) <= win.crow_last;
+        const bool cl2 = cl && (y & 1);
+        const unsigned at = (unsigned)(I - fo.crb) * fo.cpitch_bytes + fo.clane_off;
+#pragma unroll
+        for (int k = 0; k <= CW; ++k) pe.a[k] = bload1((T*)nullptr, fo.ce, cl ? at + (unsigned)(k * sizeof(T)) : kOobOffset);
+#pragma unroll
+        for (int k = 0; k <= CW; ++k) pe.b[k] = bload1((T*)nullptr, fo.ce, cl2 ? at + fo.cpitch_bytes + (unsigned)(k * sizeof(T)) : kOobOffset);
+    }
 }
 
 // loads of one step of k_jacobi_cycle (whole grids: rows 0..N exist)
@@ -983,7 +1053,7 @@ template <typename T, bool EDGE, bool ZIN = false>
 __device__ __forceinline__ void
 cycle_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
             const T* __restrict__ pv, const T* __restrict__ pb, long pitch, int N, int y_end, bool ld, bool zero_in,
-            const CycleWin& win)
+            const CycleWin& win, const FastOut& fo)
 {
     using V = typename VecOf<T>::type;
     if constexpr (!EDGE) {
@@ -991,13 +1061,13 @@ cycle_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
         if constexpr (ZIN) in = vzero((V*)nullptr);
         else in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
         bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
-        return;
-    }
-    if (EDGE) {
-        // win.row_first >= 0 and win.row_last <= N: the window also keeps y inside the grid
-        in = vload<V>(pv + (long)y * pitch, ld && !zero_in && y >= win.row_first && y <= win.row_last && y < y_end);
-        bn = vload<V>(pb + (long)(y - 1) * pitch, ld && (y - 1) > 0 && (y - 1) < N && (y - 1) >= win.row_first &&
-                                                   (y - 1) <= win.row_last && y <= y_end);
+    } else {
+        // edge body: no branch either - a row or lane that must not be read reads 0 through the
+        // descriptor (win.row_first >= 0 and win.row_last <= N: the window also keeps y inside the grid)
+        const bool in_ok = !zero_in && y >= win.row_first && y <= win.row_last && y < y_end;
+        const bool b_ok = (y - 1) > 0 && (y - 1) < N && (y - 1) >= win.row_first && (y - 1) <= win.row_last && y <= y_end;
+        in = bload((V*)nullptr, fo.in, (ld && in_ok) ? (unsigned)(y - fo.rb) * fo.pitch_bytes + fo.lane_off : kOobOffset);
+        bn = bload((V*)nullptr, fo.rhs, (ld && b_ok) ? (unsigned)(y - 1 - fo.rb) * fo.pitch_bytes + fo.lane_off : kOobOffset);
     }
 }
 
@@ -1068,7 +1138,6 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     constexpr int S_OLD = (P + 1) % 3, S_MID = (P + 2) % 3, S_NEW = P;
     constexpr int bnd_lo = 0;
     const int bnd_hi = N;
-    const V Z = vzero((V*)nullptr);
     const int r0 = ca.r0, r1 = ca.r1;
 
     // input row y and rhs row y-1 were loaded during the previous step (software
@@ -1077,7 +1146,8 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     const V bn = nbn[0];
 #pragma unroll
     for (int q = 0; q + 1 < kPfStages; ++q) { nin[q] = nin[q + 1]; nbn[q] = nbn[q + 1]; }
-    cycle_loads<T, EDGE, ZIN>(nin[kPfStages - 1], nbn[kPfStages - 1], y + cycle_pfd<BL, POST>(), pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win);
+    cycle_loads<T, EDGE, ZIN>(nin[kPfStages - 1], nbn[kPfStages - 1], y + cycle_pfd<BL, POST>(), pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win, fo);
+    const ColMask cm = col_mask(col, N);
     if (PRE) {
         // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624).  The coarse
         // values of row y were fetched during the previous step (pe.a = coarse row y>>1,
@@ -1085,8 +1155,8 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
         T a[CW + 1], b2[CW + 1], o[W];
 #pragma unroll
         for (int k = 0; k <= CW; ++k) { a[k] = pe.a[k]; b2[k] = pe.b[k]; }
-        coarse_loads<T, EDGE>(pe, y + cycle_cpfd<T, BL, EDGE, POST>(), coarse_e, ca.cpitch, ccol, N, cld, ca.win);
-        if constexpr (!EDGE) {
+        coarse_loads<T, EDGE>(pe, y + cycle_cpfd<T, BL, EDGE, POST>(), coarse_e, ca.cpitch, ccol, N, cld, ca.win, fo);
+        {
             // branch-free: both row parities evaluated (same expressions, same order), one selected
             const bool even = (y & 1) == 0;
 #pragma unroll
@@ -1098,20 +1168,11 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
                 o[2 * k] = even ? a[k] : od0;
                 o[2 * k + 1] = even ? ev1 : od1;
             }
-        } else if ((y & 1) == 0) {
-#pragma unroll
-            for (int k = 0; k < CW; ++k) { o[2 * k] = a[k]; o[2 * k + 1] = (T)0.5 * (a[k] + a[k + 1]); }
-        } else {
-#pragma unroll
-            for (int k = 0; k < CW; ++k) {
-                o[2 * k] = (T)0.5 * (a[k] + b2[k]);
-                o[2 * k + 1] = (T)0.25 * (((a[k] + b2[k]) + a[k + 1]) + b2[k + 1]);
-            }
         }
         V add;
         if constexpr (W == 2) add = make_double2(o[0], o[1]);
         else add = make_float4(o[0], o[1], o[2], o[3]);
-        if (EDGE) mask_cols(add, col, N);
+        if constexpr (EDGE) mask_sel(add, cm, false);
         if constexpr (W == 2) { in.x = in.x + add.x; in.y = in.y + add.y; }
         else { in.x = in.x + add.x; in.y = in.y + add.y; in.z = in.z + add.z; in.w = in.w + add.w; }
     }
@@ -1163,17 +1224,10 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
         if constexpr (PREMUL) o = jacobi_vec_pre(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], cb, c0, c1);
         else o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], cb, c0, c1,
                                  row + (int)(col & 1));
-        if (EDGE) {
-            mask_cols(o, col, N);
-            if (!(row > bnd_lo && row < bnd_hi)) o = Z;
-        }
+        if constexpr (EDGE) mask_sel(o, cm, !(row > bnd_lo && row < bnd_hi));     // Dirichlet rows and columns stay zero
         if constexpr (j == K) {
-            if constexpr (!EDGE) {
-                const unsigned at = (unsigned)row * fo.pitch_bytes + fo.lane_off;
-                bstore(o, fo.out, (st && row >= r0 && row < r1) ? at : kOobOffset);
-            } else {
-                vstore<V>(po + (long)row * pitch, o, st && row >= r0 && row < r1);
-            }
+            const unsigned at = (unsigned)(row - fo.rb) * fo.pitch_bytes + fo.lane_off;
+            bstore(o, fo.out, (st && row >= r0 && row < r1) ? at : kOobOffset);
         }
         if (j < K || POST) lev[j][S_NEW] = o;
     });
@@ -1181,20 +1235,13 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
         // residual of the new iterate on row rho = y-K-1 (rows rho-1, rho, rho+1 of level K)
         const int rho = y - K - 1;
         V res = residual_vec(lev[K][S_OLD], lev[K][S_MID], lev[K][S_NEW], bwin(std::integral_constant<int, K>{}));
-        if (EDGE) {
-            mask_cols(res, col, N);
-            if (!(rho > bnd_lo && rho < bnd_hi)) res = Z;
-        }
+        if constexpr (EDGE) mask_sel(res, cm, !(rho > bnd_lo && rho < bnd_hi));
         if (POST == 2) {
             double r2;
             if constexpr (W == 2) r2 = (double)res.x * (double)res.x + (double)res.y * (double)res.y;
             else r2 = ((double)res.x * (double)res.x + (double)res.y * (double)res.y) +
                       ((double)res.z * (double)res.z + (double)res.w * (double)res.w);
-            if constexpr (!EDGE) {
-                cs.acc += (st && rho >= r0 && rho < r1) ? r2 : 0.0;      // + 0.0 is exact: same sum, no branch
-            } else {
-                if (st && rho >= r0 && rho < r1) cs.acc += r2;
-            }
+            cs.acc += (st && rho >= r0 && rho < r1) ? r2 : 0.0;          // + 0.0 is exact: same sum, no branch
         } else {
             T cl[CW], cc[CW], cr[CW];          // this row's residual left / centre / right per coarse column
             const T l = from_left(last(res));
@@ -1214,21 +1261,12 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
                 T corners = cs.ct[k] + cl[k]; corners = corners + cr[k];
                 const T edges = cs.em[k] + cc[k];
                 o[k] = wgt * ((corners + (T)2 * edges) + (T)4 * cs.mc[k]);
-                if (EDGE && (ccol + k == 0 || ccol + k >= ca.NC)) o[k] = (T)0;
+                if constexpr (EDGE) o[k] = (ccol + k == 0 || ccol + k >= ca.NC) ? (T)0 : o[k];
             }
-            if constexpr (!EDGE) {
-                const unsigned at = (st && emit) ? ((unsigned)I * fo.cpitch_bytes + fo.clane_off) : kOobOffset;
+            {
+                const unsigned at = (st && emit) ? ((unsigned)(I - fo.crb) * fo.cpitch_bytes + fo.clane_off) : kOobOffset;
                 if constexpr (CW == 1) { bstore8(o[0], fo.cb, at); bstore8((T)0, fo.cz, at); }
                 else { bstore8(make_float2((float)o[0], (float)o[1]), fo.cb, at); bstore8(make_float2(0.f, 0.f), fo.cz, at); }
-            } else if (st && emit) {
-                T* pc = coarse_b + (long)I * ca.cpitch + ccol;
-                if constexpr (CW == 1) { pc[0] = o[0]; }
-                else { *reinterpret_cast<float2*>(pc) = make_float2((float)o[0], (float)o[1]); }
-                if (coarse_zero) {
-                    T* pz = coarse_zero + (long)I * ca.cpitch + ccol;
-                    if constexpr (CW == 1) { pz[0] = (T)0; }
-                    else { *reinterpret_cast<float2*>(pz) = make_float2(0.f, 0.f); }
-                }
             }
 #pragma unroll
             for (int k = 0; k < CW; ++k) {
@@ -1280,20 +1318,23 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     // rounded up to whole rotations; the deep (BL) bodies run whole kBRing-step trips with no exit in
     // between - a branch-free trip is what lets the compiler keep several rows in flight - and the
     // launcher picks the chunk height so that nothing (or one step) is wasted
-    constexpr int kRound = BL ? kBRing : (EDGE ? 3 : trip_steps<T>());
+    constexpr int kRound = BL ? kBRing : trip_steps<T>();
     const int steps = (ca.y_end - y0 + kRound - 1) / kRound * kRound;
     constexpr int PFD = cycle_pfd<BL, POST>();
     V nin[PFD][kPfStages], nbn[PFD][kPfStages];    // [step phase mod PFD][queue position]
-#pragma unroll
-    for (int q = 0; q < PFD; ++q)
-        cycle_loads<T, EDGE, ZIN>(nin[q][0], nbn[q][0], y0 + q, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win);
     constexpr int CPFD = cycle_cpfd<T, BL, EDGE, POST>();
     PreFetch<T, CW> pe[CPFD];                       // [step phase mod CPFD]
 #pragma unroll
     for (int q = 0; q < CPFD; ++q) {
 #pragma unroll
         for (int k = 0; k <= CW; ++k) { pe[q].a[k] = (T)0; pe[q].b[k] = (T)0; }
-        if (PRE) coarse_loads<T, EDGE>(pe[q], y0 + q, coarse_e, cpitch, ccol, N, cld, ca.win);
+    }
+#pragma unroll
+    for (int q = 0; q < PFD; ++q)
+        cycle_loads<T, EDGE, ZIN>(nin[q][0], nbn[q][0], y0 + q, pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win, fo);
+    if (PRE) {
+#pragma unroll
+        for (int q = 0; q < CPFD; ++q) coarse_loads<T, EDGE>(pe[q], y0 + q, coarse_e, cpitch, ccol, N, cld, ca.win, fo);
     }
 #define MGX_CSTEP(RP, Y) cycle_step<T, K, PRE, POST, SM, EDGE, RP, BL, ZIN>(lev, bw, ring, nin[(RP) % PFD], nbn[(RP) % PFD], pe[(RP) % CPFD], cs, Y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1, fo)
     if constexpr (BL) {
@@ -1304,7 +1345,7 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
             MGX_CSTEP(6, y + 6); MGX_CSTEP(7, y + 7); MGX_CSTEP(8, y + 8);
             MGX_CSTEP(9, y + 9); MGX_CSTEP(10, y + 10); MGX_CSTEP(11, y + 11);
         }
-    } else if constexpr (!EDGE && trip_steps<T>() == 12) {
+    } else if constexpr (trip_steps<T>() == 12) {
         for (int y = y0; y < y0 + steps; y += 12) {
             MGX_CSTEP(0, y); MGX_CSTEP(1, y + 1); MGX_CSTEP(2, y + 2);
             MGX_CSTEP(3, y + 3); MGX_CSTEP(4, y + 4); MGX_CSTEP(5, y + 5);
@@ -1364,18 +1405,25 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         bool interior = (vx0 >= 1) && ((long)(vx0 + kWave + 1) * W < N) &&
                         (y_first > 0) && (y_lastp < N) && (y_first >= win.row_first) && (y_lastp <= win.row_last);
         if (PRE) interior = interior && (y_first >> 1) >= win.crow_first && ((y_lastp >> 1) + 1) <= win.crow_last;
-        // the interior bodies store through 32-bit buffer offsets: the rows that exist must end below 4 GiB
-        const unsigned long out_bytes = (unsigned long)(win.row_last + 1) * (unsigned long)pitch * sizeof(T);
-        const unsigned long cb_bytes = (unsigned long)(win.crow_last + 1) * (unsigned long)cpitch * sizeof(T);
-        interior = interior && out_bytes < 0xFFFFF000ul && !(PRE != 0 && zero_in);
+        interior = interior && !(PRE != 0 && zero_in);
+        // both bodies store (and the edge body loads) through buffer descriptors that start at the first
+        // row this wave can touch, with 32-bit offsets relative to it
         FastOut fo;
-        fo.out = make_rsrc(vout, (unsigned)out_bytes);
-        fo.cb = make_rsrc(coarse_b, (POST == 1 && coarse_b) ? (unsigned)cb_bytes : 0u);
-        fo.cz = make_rsrc(coarse_zero, (POST == 1 && coarse_zero) ? (unsigned)cb_bytes : 0u);   // empty: every store dropped
-        fo.lane_off = (unsigned)(col * (long)sizeof(T));
-        fo.clane_off = (unsigned)((col / 2) * (long)sizeof(T));
+        fo.rb = max(y_first, win.row_first);
+        fo.crb = max(y_first >> 1, win.crow_first);
         fo.pitch_bytes = (unsigned)(pitch * (long)sizeof(T));
         fo.cpitch_bytes = (unsigned)(cpitch * (long)sizeof(T));
+        const unsigned f_bytes = rsrc_bytes(fo.rb, win.row_last, fo.pitch_bytes);
+        const unsigned c_bytes = rsrc_bytes(fo.crb, win.crow_last, fo.cpitch_bytes);
+        const long f_at = (long)fo.rb * pitch, c_at = (long)fo.crb * cpitch;
+        fo.out = make_rsrc(vout + f_at, f_bytes);
+        fo.in = make_rsrc(vin + f_at, f_bytes);
+        fo.rhs = make_rsrc(rhs + f_at, f_bytes);
+        fo.ce = make_rsrc(PRE ? coarse_e + c_at : nullptr, (PRE && coarse_e) ? c_bytes : 0u);
+        fo.cb = make_rsrc((POST == 1 && coarse_b) ? coarse_b + c_at : nullptr, (POST == 1 && coarse_b) ? c_bytes : 0u);
+        fo.cz = make_rsrc((POST == 1 && coarse_zero) ? coarse_zero + c_at : nullptr, (POST == 1 && coarse_zero) ? c_bytes : 0u);   // empty: every store dropped
+        fo.lane_off = (unsigned)(col * (long)sizeof(T));
+        fo.clane_off = (unsigned)((col / 2) * (long)sizeof(T));
         if (interior) {
             if (PRE == 0 && zero_in)
                 acc = cycle_body<T, K, PRE, POST, SM, false, PRE == 0>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
