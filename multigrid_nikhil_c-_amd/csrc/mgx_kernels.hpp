@@ -186,6 +186,12 @@ __device__ __forceinline__ unsigned rsrc_bytes(int first, int last, unsigned lon
     const unsigned long b = (unsigned long)(last - first + 1) * row_bytes;
     return b < 0x7FFFFF00ul ? (unsigned)b : 0x7FFFFF00u;
 }
+// A uniform value the optimizer cannot see through.  The edge bodies test every level's row against
+// the Dirichlet rows; row y-j of step y is row (y+1)-(j+1) of the next step, and with the trip fully
+// unrolled the compiler computes each row's lane masks once and keeps them alive for K steps: 40+
+// live SGPR pairs, ~150 spilled to VGPR lanes, the VGPRs in turn to scratch.  Recomputing a mask per
+// level costs a few scalar instructions.
+__device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
 // column masks of a lane: its first column is the Dirichlet column 0 / its columns lie at or beyond column N
 struct ColMask { bool first, all; };
 __device__ __forceinline__ ColMask col_mask(long col, int N) { return ColMask{col == 0, col >= N}; }
@@ -591,6 +597,7 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
     // register moves either); refill the slot with the rows of step y+3 before computing.
     // Three rows in flight per wave instead of one: a marching wave has no other way to
     // cover the HBM latency.
+    if constexpr (EDGE) __builtin_amdgcn_sched_barrier(0);     // see cycle_step
     const V in = nin[0], bn = nbn[0];
 #pragma unroll
     for (int q = 0; q + 1 < kPfStages; ++q) { nin[q] = nin[q + 1]; nbn[q] = nbn[q + 1]; }
@@ -608,7 +615,10 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
         V o;
         if constexpr (SM == 0) o = jacobi_vec_pre(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1);
         else o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1, par_c + row);
-        if constexpr (EDGE) mask_sel(o, cm, !(row > bnd_lo && row < bnd_hi));     // Dirichlet rows and columns stay zero
+        if constexpr (EDGE) {                                                      // Dirichlet rows and columns stay zero
+            const int rw = opaque_s(row);
+            mask_sel(o, cm, !(rw > bnd_lo && rw < bnd_hi));
+        }
         if (j < K) {
             lev[j][S_NEW] = o;
         } else {
@@ -1112,7 +1122,8 @@ constexpr int ring_slot(int m) { return ((m % kBRing) + kBRing) % kBRing; }
 // everywhere, except the deep pre-smoothing passes with the restriction stage: they are the most
 // register-hungry kernels of the library, a step of theirs is ~800 vector instructions long, and two
 // rows in flight keep them at two waves per SIMD without spills.
-template <bool BL, int POST> constexpr int cycle_pfd() { return (BL && POST == 1) ? 2 : kPrefetch; }
+// (the deep edge bodies, with their masks on top, too: the 10-level correction pass spilled with three)
+template <bool BL, int POST, bool EDGE = false> constexpr int cycle_pfd() { return (BL && (POST == 1 || EDGE)) ? 2 : kPrefetch; }
 // rows the coarse correction (PRE) is fetched ahead.  vmcnt counts in issue order, so waiting for a
 // coarse row fetched ONE step ago also waits for every fine row issued before it: with a one-step
 // coarse prefetch the three-row fine prefetch was worth one row.  The interior bodies fetch the
@@ -1140,13 +1151,16 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     const int bnd_hi = N;
     const int r0 = ca.r0, r1 = ca.r1;
 
+    // (edge bodies: left alone, the scheduler computes the load offsets and row masks of all the steps
+    // of a trip at its top - some 70 VGPRs and 150 spilled SGPRs - so each step is fenced)
+    if constexpr (EDGE) __builtin_amdgcn_sched_barrier(0);
     // input row y and rhs row y-1 were loaded during the previous step (software
     // prefetch, see fused_step); issue the next step's loads before computing
     V in = nin[0];
     const V bn = nbn[0];
 #pragma unroll
     for (int q = 0; q + 1 < kPfStages; ++q) { nin[q] = nin[q + 1]; nbn[q] = nbn[q + 1]; }
-    cycle_loads<T, EDGE, ZIN>(nin[kPfStages - 1], nbn[kPfStages - 1], y + cycle_pfd<BL, POST>(), pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win, fo);
+    cycle_loads<T, EDGE, ZIN>(nin[kPfStages - 1], nbn[kPfStages - 1], y + cycle_pfd<BL, POST, EDGE>(), pv, pb, pitch, N, ca.y_end, ld, ca.zero_in, ca.win, fo);
     const ColMask cm = col_mask(col, N);
     if (PRE) {
         // v + P e on unknown rows, exactly as k_prolong<T,true> (PS:620-624).  The coarse
@@ -1224,7 +1238,10 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
         if constexpr (PREMUL) o = jacobi_vec_pre(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], cb, c0, c1);
         else o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], cb, c0, c1,
                                  row + (int)(col & 1));
-        if constexpr (EDGE) mask_sel(o, cm, !(row > bnd_lo && row < bnd_hi));     // Dirichlet rows and columns stay zero
+        if constexpr (EDGE) {                                                      // Dirichlet rows and columns stay zero
+            const int rw = opaque_s(row);
+            mask_sel(o, cm, !(rw > bnd_lo && rw < bnd_hi));
+        }
         if constexpr (j == K) {
             const unsigned at = (unsigned)(row - fo.rb) * fo.pitch_bytes + fo.lane_off;
             bstore(o, fo.out, (st && row >= r0 && row < r1) ? at : kOobOffset);
@@ -1235,7 +1252,10 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
         // residual of the new iterate on row rho = y-K-1 (rows rho-1, rho, rho+1 of level K)
         const int rho = y - K - 1;
         V res = residual_vec(lev[K][S_OLD], lev[K][S_MID], lev[K][S_NEW], bwin(std::integral_constant<int, K>{}));
-        if constexpr (EDGE) mask_sel(res, cm, !(rho > bnd_lo && rho < bnd_hi));
+        if constexpr (EDGE) {
+            const int rw = opaque_s(rho);
+            mask_sel(res, cm, !(rw > bnd_lo && rw < bnd_hi));
+        }
         if (POST == 2) {
             double r2;
             if constexpr (W == 2) r2 = (double)res.x * (double)res.x + (double)res.y * (double)res.y;
@@ -1320,7 +1340,7 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     // launcher picks the chunk height so that nothing (or one step) is wasted
     constexpr int kRound = BL ? kBRing : trip_steps<T>();
     const int steps = (ca.y_end - y0 + kRound - 1) / kRound * kRound;
-    constexpr int PFD = cycle_pfd<BL, POST>();
+    constexpr int PFD = cycle_pfd<BL, POST, EDGE>();
     V nin[PFD][kPfStages], nbn[PFD][kPfStages];    // [step phase mod PFD][queue position]
     constexpr int CPFD = cycle_cpfd<T, BL, EDGE, POST>();
     PreFetch<T, CW> pe[CPFD];                       // [step phase mod CPFD]
