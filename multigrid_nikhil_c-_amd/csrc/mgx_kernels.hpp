@@ -1359,12 +1359,11 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
 #define MGX_CSTEP(RP, Y) cycle_step<T, K, PRE, POST, SM, EDGE, RP, BL, ZIN>(lev, bw, ring, nin[(RP) % PFD], nbn[(RP) % PFD], pe[(RP) % CPFD], cs, Y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1, fo)
     if constexpr (BL) {
         // kBRing steps per trip so that every ring slot is a compile-time offset
-        for (int y = y0; y < y0 + steps; y += kBRing) {
-            MGX_CSTEP(0, y); MGX_CSTEP(1, y + 1); MGX_CSTEP(2, y + 2);
-            MGX_CSTEP(3, y + 3); MGX_CSTEP(4, y + 4); MGX_CSTEP(5, y + 5);
-            MGX_CSTEP(6, y + 6); MGX_CSTEP(7, y + 7); MGX_CSTEP(8, y + 8);
-            MGX_CSTEP(9, y + 9); MGX_CSTEP(10, y + 10); MGX_CSTEP(11, y + 11);
-        }
+#define MGX_CTRIP(Y) do { MGX_CSTEP(0, Y); MGX_CSTEP(1, Y + 1); MGX_CSTEP(2, Y + 2); MGX_CSTEP(3, Y + 3); MGX_CSTEP(4, Y + 4); \
+                          MGX_CSTEP(5, Y + 5); MGX_CSTEP(6, Y + 6); MGX_CSTEP(7, Y + 7); MGX_CSTEP(8, Y + 8); MGX_CSTEP(9, Y + 9); \
+                          MGX_CSTEP(10, Y + 10); MGX_CSTEP(11, Y + 11); } while (0)
+        for (int y = y0; y < y0 + steps; y += kBRing) MGX_CTRIP(y);
+#undef MGX_CTRIP
     } else if constexpr (trip_steps<T>() == 12) {
         for (int y = y0; y < y0 + steps; y += 12) {
             MGX_CSTEP(0, y); MGX_CSTEP(1, y + 1); MGX_CSTEP(2, y + 2);
