@@ -1459,7 +1459,7 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
         // kernel (k_jacobi_rows) reads them without asking whether they exist
         const int lo = std::max(std::max(row_lo - ext, first), 1), hi = std::min(std::min(row_hi + ext, last), f->rows - 1);
         if (hi > lo) {
-            const int R = fuse_rows(fc, N, K, sizeof(T) == 8);
+            const int R = fuse_rows(fc, N, K, sizeof(T) == 8, hi - lo);
             if (P || Q) {
                 if (!cycle_k_supported(K, rbgs, sizeof(T) == 8, Q, P)) return MGX_ERR_INVALID;
                 fa.row_lo = lo + f->row0; fa.row_hi = hi + f->row0;

@@ -132,14 +132,30 @@ bool launch_fused(int K, const T* vin, const T* b, T* vout, int N, long pitch, i
 // 2048^2); K >= 5: N/128 clamped to [8, 64] in double (flat between 48 and 96 at 8192^2), to
 // [8, 32] in float (a float wave covers twice the columns, so a grid has half the strips:
 // 8192^2 fp32 V(10,10) finest level 0.96 -> 0.90 ms at 32 rows)
-inline int fuse_rows(const FuseCfg& fc, int N, int K, bool f64 = true)
+// deep double passes (K >= 8: two workgroups of four waves per CU = 2048 waves per round): whole
+// rounds.  One wave per (chunk, strip of 52-54 vectors): with cpr = 2048 / strips chunk rows per round,
+// `rows` rows in m rounds take R = rows / (m cpr); m = the fewest rounds with R <= 200.  Measured (one
+// pass, us): 4096^2 whole 183 at 36 rows, 154 at 84 (m = 1, 490 workgroups), 167-190 at 48-72 and
+// 90-108; 16384^2 whole 1947 at 72, 1807 at 200; 8192^2 whole 487-498 at 72 and 484-492 at 168 (flat; on
+// a box that clocks down under the f64 load, 540 against 492).  Fewer, taller chunks also recompute
+// fewer halo rows (2K + 3 per chunk).
+inline int fuse_rows_deep(int N, int rows)
+{
+    const int strips = (N / 2 + 51) / 52;
+    const int cpr = std::max(1, 2048 / strips);
+    for (int m = 1; m <= 64; ++m) {
+        const int R = (rows + m * cpr - 1) / (m * cpr);
+        if (R <= 200) return std::max(R, 16);
+    }
+    return 64;
+}
+
+inline int fuse_rows(const FuseCfg& fc, int N, int K, bool f64 = true, int rows = 0)
 {
     if (fc.rows > 0) return fc.rows;
     if (K <= 2) return 8;
     if (K <= 4) return N >= 8192 ? 24 : 16;
-    // 4096^2 in double: 84 rows make the 10-level pass exactly one round of 490 workgroups (2 per CU);
-    // measured 0.154 ms per pass against 0.183 at 36 rows and 0.167-0.19 at 48-72 and 90-108
-    if (f64 && N == 4096 && K >= 8) return 84;
+    if (f64 && K >= 8 && N >= 2048) return fuse_rows_deep(N, rows > 0 ? rows : N - 1);
     int R = N / 128;
     if (R < 8) R = 8;
     if (R > (f64 ? 64 : 32)) R = f64 ? 64 : 32;
@@ -267,7 +283,7 @@ int smooth_block(int smoother, T* a, const T* rhs, T* b2, int N, long pitch, int
             } else if (rbgs && !allow_fuse) {
                 launch_rbgs<T>(src, rhs, dst, N, pitch, lo, hi, row_parity, bl, bh, rpc, st);
             } else {
-                const int R = fuse_rows(fc, N, K, sizeof(T) == 8);
+                const int R = fuse_rows(fc, N, K, sizeof(T) == 8, hi - lo);
                 const bool ok = rbgs ? launch_fused<T, 1>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st, rows_alloc)
                                      : launch_fused<T, 0>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st, rows_alloc);
                 if (!ok) return MGX_ERR_INVALID;
