@@ -1,0 +1,15 @@
+#!/bin/bash
+mkdir -p gpurun_out/r02
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/r02/w_tests.log 2>&1 || { tail -40 gpurun_out/r02/w_tests.log; exit 1; }
+tail -3 gpurun_out/r02/w_tests.log
+for v in new prev new prev; do
+  if [ $v = prev ]; then export MGX_LIBMGX_PATH=$PWD/tools/ab/libmgx_prev.so; else unset MGX_LIBMGX_PATH; fi
+  for L in 13 10; do
+    python bench.py --no-cpu-baseline --level $L --steps 20 --warmup 3 > gpurun_out/r02/bench_w_${v}_$L.json 2>/dev/null || exit 1
+    python - "gpurun_out/r02/bench_w_${v}_$L.json" "$v L$L" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+print(sys.argv[2], round(d["ms_per_step"],4), {k:round(v,4) for k,v in d["phase_ms_per_step"].items() if k in ("smooth_fine","coarse_levels")}, round(d["roofline"]["avg_launch_ms"],4))
+PY
+  done
+done
