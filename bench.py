@@ -158,7 +158,9 @@ def run_single(args):
     n = (1 << L) - 1
     cfg = dict(finest_level=L, coarsest_level=min(args.coarsest, L), mu0=0, mu1=args.mu1, mu2=args.mu2,
                omega=args.omega, smoother=1 if args.smoother == "rbgs" else 0, dtype=DT[args.dtype],
-               schedule=pkg.SCHEDULE_V, profile=1)
+               schedule=pkg.SCHEDULE_V, profile=2)
+    # profile = 2: the finest level's passes are launched one by one between HIP events, the rest of the
+    # cycle is one hipGraph replay between two events (include/mgx.h) - mgx_solve's own execution, timed
     mg = pkg.Multigrid(**cfg)
     # synthetic input, generated on the device: resident in HBM before any timing
     mg.fill_rhs(1, 0.0)               # b = h^2 8 pi^2 sin(2 pi x) sin(2 pi y)
@@ -258,7 +260,8 @@ def run_single(args):
             "launches_timed": sm_launches,
             "sweeps_timed": sm_sweeps,
             "smoother_updates_per_s": n * n * sm_sweeps / (sm_ms * 1e-3),
-            "how": "HIP events on the solver's stream around every finest-level smoothing block inside the timed steps",
+            "how": "HIP events on the solver's stream around every finest-level smoothing block inside the timed steps "
+                   "(cfg.profile = 2: those passes launched one by one, the levels below replayed from one hipGraph)",
         },
         "phase_ms_per_step": {
             "smooth_fine": prof["ms"][0] / args.steps, "restrict_fine": prof["ms"][1] / args.steps,

@@ -66,7 +66,10 @@ typedef struct {
     int restrict_mode;    /* MGX_RESTRICT_*   */
     int bottom;           /* MGX_BOTTOM_*    (EXACT: MF:137-139; SMOOTH: PS:581-587, D8) */
     int device;           /* HIP device ordinal (n_gpus <= 1) */
-    int profile;          /* 1: record HIP events around each operator class */
+    int profile;          /* 1: HIP events around each operator class, every launch eager (no graph replay);
+                             2: events around the finest level's passes, launched one by one, and around ONE
+                                graph replay of everything below it (what bench.py times: mgx_solve's own
+                                execution, less the two kernel boundaries a whole-cycle graph saves) */
     /* ---- multi-GPU (the reference has one sycl::queue, PS:659) -------------
      * n_gpus > 1: the levels above cut_level are split into n_gpus row slabs, slab g on device
      * devices[g]; one stream pair per slab, halo rows moved device to device between the
@@ -204,7 +207,7 @@ typedef struct {
     long long sweeps[MGX_PROF_COUNT];   /* smoother sweeps those launches performed (a fused
                                            launch does several; 0 for non-smoother classes) */
 } mgx_profile;
-/* Valid when cfg.profile = 1; events are recorded on the handle's stream. */
+/* Valid when cfg.profile = 1 or 2; events are recorded on the handle's stream. */
 MGX_API int mgx_profile_reset(mgx_handle h);
 MGX_API int mgx_profile_get(mgx_handle h, mgx_profile* out);
 /* `sweeps` finest-level smoother sweeps bracketed by HIP events on the

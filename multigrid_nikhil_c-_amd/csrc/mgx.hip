@@ -78,6 +78,7 @@ struct mgx_solver {
     };
     std::vector<CycleGraph> graphs;
     int use_graph = 1;              // MGX_GRAPH
+    bool prof_mute = false;         // inside a stream capture: no events (they carry no time stamps there)
     int mixed_fuse = 1;             // mixed precision: u += s e and the residual in one pass (MGX_MIXED_FUSE)
     struct mgx_dist* dist = nullptr; // multi-GPU handle (cfg.n_gpus > 1 / mgx_create_rank): mgx_dist.hpp; no levels of its own
 
@@ -98,7 +99,7 @@ struct Prof {
     mgx_solver* s; int idx = -1;
     Prof(mgx_solver* s_, int cls, long long launches) : s(s_)
     {
-        if (!s->cfg.profile) return;
+        if (!s->cfg.profile || s->prof_mute) return;
         EventPair p;
         if (!s->ev_free.empty()) { p = s->ev_free.back(); s->ev_free.pop_back(); }
         else { if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; }
@@ -630,8 +631,92 @@ int cycle_body_direct(mgx_solver* s, bool want_norm, bool zero_start, double* r)
     return residual_norm_grid(s, l, l.u, l.b, r, MGX_PROF_NORM_FINE);
 }
 
+// cfg.profile = 2: the finest level's passes are launched one by one between HIP events (they are
+// long: the host runs ahead of them) and everything below the finest level is ONE graph replay
+// between two events.  Events recorded inside a captured graph carry no time stamps on this runtime
+// (hipEventElapsedTime: invalid resource handle - tools/probe/graph_events.hip), so this is how the
+// dominant kernel is timed with HIP events while the cycle still runs the way mgx_solve runs it
+// (cfg.profile = 1, every launch eager: 1.62 instead of 1.52 ms per cycle at 8192^2).
+int coarse_part_graph(mgx_solver* s, int level)
+{
+    std::vector<void*> before = buffer_state(s);
+    before.push_back(reinterpret_cast<void*>((uintptr_t)(4 | (s->zero_in_level == level ? 8 : 0))));
+    mgx_solver::CycleGraph* g = nullptr;
+    for (auto& c : s->graphs)
+        if (c.before == before) { g = &c; break; }
+    if (!g) {
+        if (s->graphs.size() >= 8 || hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            vcycle(s, level);
+            return MGX_OK;
+        }
+        const double fu0 = s->fine_updates;
+        const std::vector<void*> state0 = buffer_state(s);
+        const int zin0 = s->zero_in_level;
+        s->prof_mute = true;
+        vcycle(s, level);
+        s->prof_mute = false;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipError_t e = hipStreamEndCapture(s->stream, &graph);
+        if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_buffer_state(s, state0);
+            s->fine_updates = fu0;
+            s->zero_in_level = zin0;
+            s->use_graph = 0;
+            vcycle(s, level);
+            return MGX_OK;
+        }
+        mgx_solver::CycleGraph c;
+        c.before = before; c.after = buffer_state(s); c.exec = exec; c.fine_updates = s->fine_updates - fu0;
+        s->graphs.push_back(c);
+        g = &s->graphs.back();
+    } else {
+        set_buffer_state(s, g->after);
+        s->fine_updates += g->fine_updates;
+    }
+    s->zero_in_level = -1;
+    Prof p(s, MGX_PROF_COARSE, 1);
+    HIPCHK(s, hipGraphLaunch(g->exec, s->stream));
+    return MGX_OK;
+}
+
+int cycle_body_split(mgx_solver* s, bool want_norm, bool zero_start, double* r)
+{
+    const int L = s->cfg.finest_level;
+    Level& l = s->lv[L];
+    s->norm_blocks_ready = 0;
+    s->want_norm = false; s->zero_in_level = -1;
+    bool zin_here = false;
+    if (zero_start) {
+        if (zero_in_ok(s, L)) zin_here = true;
+        else { int rc = zero_u(s, L); if (rc) return rc; }
+    }
+    // the finest level's half of vcycle() (PS:581, 604-613), launch by launch
+    const bool zin_next = zero_in_ok(s, L - 1);
+    if (zin_next) s->zero_in_level = L - 1;                       // (the pre-smoothing pass then leaves the coarse guess alone)
+    if (!smooth_folded(s, L, s->cfg.mu1, false, 1, zin_here)) {
+        if (zin_here) (void)zero_u(s, L);
+        smooth(s, L, s->cfg.mu1);
+        restrict_level(s, L, true, !zin_next);
+    }
+    int rc = coarse_part_graph(s, L - 1);                         // PS:617
+    if (rc) return rc;
+    if (!smooth_folded(s, L, s->cfg.mu2, true, want_norm ? 2 : 0)) {   // PS:620-625 (+ the norm's sums)
+        prolong_level(s, L, true);
+        smooth(s, L, s->cfg.mu2);
+    }
+    if (!want_norm) return MGX_OK;
+    return residual_norm_grid(s, l, l.u, l.b, r, MGX_PROF_NORM_FINE);
+}
+
 int cycle_body(mgx_solver* s, bool want_norm, bool zero_start, double* r)
 {
+    if (s->cfg.profile == 2 && s->use_graph && !s->mixed && s->cfg.finest_level > s->cfg.coarsest_level)
+        return cycle_body_split(s, want_norm, zero_start, r);
     if (!s->use_graph || s->cfg.profile || s->mixed) return cycle_body_direct(s, want_norm, zero_start, r);
     const int L = s->cfg.finest_level;
     std::vector<void*> before = buffer_state(s);
@@ -889,7 +974,7 @@ int mgx_graphs_cached(mgx_handle s)
         mgx_handle c = s->dist->slabs[0].coarse;
         return (c && c->use_graph) ? (int)c->graphs.size() : -1;
     }
-    if (!s->use_graph || s->cfg.profile || s->mixed) return -1;
+    if (!s->use_graph || s->cfg.profile == 1 || s->mixed) return -1;
     return (int)s->graphs.size();
 }
 

@@ -63,6 +63,32 @@ def test_profile_and_timing_entry_points(pkg):
         assert st.fine_updates == 3 * 3 * n * n and st.history_len == 4 and st.seconds > 0
 
 
+@pytest.mark.parametrize("smoother,mu1,mu2,finest", [(0, 10, 10, 11), (0, 2, 1, 10), (1, 2, 2, 10), (0, 3, 0, 9)])
+def test_profile_two_times_the_fine_passes_around_one_graph_of_the_rest(pkg, smoother, mu1, mu2, finest):
+    """cfg.profile = 2 (what bench.py times): the finest level's passes launched one by one between HIP
+    events, everything below replayed from one graph between two events - the same bits as the whole-cycle
+    graph (profile 0) and as the eager path (profile 1), graphs really cached, phases accounted"""
+    kw = dict(finest_level=finest, coarsest_level=6, mu1=mu1, mu2=mu2, smoother=smoother, schedule=0)
+    out = {}
+    for prof in (0, 1, 2):
+        with pkg.Multigrid(profile=prof, **kw) as mg:
+            mg.fill_rhs(1, 0.0)
+            mg.fill_guess_random(4242)
+            if prof:
+                mg.profile_reset()
+            st, h = mg.solve(tol=0.0, max_cycles=4)
+            out[prof] = (mg.get_solution(), h, mg.graphs_cached(), mg.profile() if prof else None, st)
+    for prof in (1, 2):
+        assert np.array_equal(out[prof][0], out[0][0])
+        assert np.allclose(out[prof][1], out[0][1], rtol=1e-13, atol=0)
+    assert out[0][2] >= 1 and out[1][2] == -1 and out[2][2] >= 1
+    p1, p2 = out[1][3], out[2][3]
+    assert p2["sweeps"][0] == p1["sweeps"][0] == 4 * (mu1 + mu2)
+    assert p2["launches"][0] == p1["launches"][0]
+    assert p2["launches"][4] == 4 and p2["ms"][4] > 0          # the coarse part: one graph launch per cycle
+    assert p2["ms"][0] > 0 and out[2][4].fine_updates == out[0][4].fine_updates
+
+
 def test_error_paths_return_status_not_crash(pkg):
     L = pkg.lib()
     with pkg.Multigrid(finest_level=8, coarsest_level=6, bottom=pkg.BOTTOM_SMOOTH) as mg:
