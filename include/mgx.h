@@ -373,7 +373,8 @@ MGX_API int mgx_create_rank(const mgx_config* cfg, int rank, int world, const vo
 /* number of halo exchanges a multi-GPU handle has performed (tests: communication plan) */
 MGX_API long mgx_dist_exchanges(mgx_handle h);
 /* how many of them ran on the slab's second stream beside the rows of the following smoothing pass that
- * need no halo (the pass then finishes with its two edge bands; MGX_DIST_OVERLAP=0 turns this off) */
+ * need no halo (the pass then finishes with its two edge bands).  Opt-in, MGX_DIST_OVERLAP=1: a band is a
+ * 10-level launch of ~50 us however thin it is, more than a halo message of this size takes */
 MGX_API long mgx_dist_overlapped(mgx_handle h);
 /* plain copies for callers that implement a transport without a HIP binding of their own */
 MGX_API int mgx_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);

@@ -57,7 +57,7 @@ struct mgx_dist {
     mgx_transport ext{};
     long exchanges = 0;
     long overlapped = 0;                     // exchanges that ran beside the interior rows of the pass they feed
-    int overlap = 1;                         // MGX_DIST_OVERLAP
+    int overlap = 0;                         // MGX_DIST_OVERLAP (off by default: DESIGN.md §7, the bands cost more than the exchange)
     double fine_updates = 0.0;
     // profiling of the finest-level smoothing blocks of the first local slab (cfg.profile)
     std::vector<EventPair> ev_used, ev_free;
@@ -224,7 +224,7 @@ int dist_create(mgx_solver* s, const mgx_config* cfg, int rank, int world, const
     if (d->cut >= cfg->finest_level || d->cut < 2)
         return s->fail(MGX_ERR_INVALID, "no level above cut_level to distribute (use a single-GPU handle)");
     const bool fold = env_int("MGX_DIST_FOLD", 1) != 0, deep = env_int("MGX_DIST_DEEP", 1) != 0;
-    d->overlap = env_int("MGX_DIST_OVERLAP", 1);
+    d->overlap = env_int("MGX_DIST_OVERLAP", 0);
     const int first = multi_process ? rank : 0, count = multi_process ? 1 : P;
     d->slabs.resize(count);
     for (int i = 0; i < count; ++i) {
