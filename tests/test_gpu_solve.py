@@ -426,3 +426,35 @@ def test_deep_folded_passes_with_the_rhs_window_in_lds_are_bit_identical(pkg, po
     assert np.allclose(h, h0, rtol=1e-13, atol=0)
     _, h_orc = po.Solver(**cfg).solve(b, u0, tol=0.0, max_cycles=2)
     assert hist_close(h, h_orc)
+
+
+def test_arrays_beyond_four_gib_folded_passes_equal_single_sweeps(pkg, monkeypatch):
+    """32768^2 in double: 8.6 GB per array, beyond what a 32-bit buffer offset reaches.  The deep folded
+    passes address rows through descriptors rebased to each wave's first row (interior stores, every load
+    and store of the edge bodies); the single-sweep kernels and stand-alone transfers (MGX_FUSE=1,
+    MGX_FOLD=0) use plain 64-bit pointers.  One V(10,10) cycle from device-generated data must give the
+    same bits both ways - also the largest grid the library accepts (finest_level 15), on one GPU."""
+    cfg = dict(finest_level=15, coarsest_level=7, mu1=10, mu2=10, schedule=0)
+    keys = ("MGX_FUSE", "MGX_FOLD", "MGX_TILE_MAX_N")
+    out = {}
+    for name, env in (("folded", {}), ("single", {"MGX_FUSE": "1", "MGX_FOLD": "0"})):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pkg.Multigrid(**cfg) as mg:
+            mg.fill_rhs(1, 0.0)
+            mg.fill_guess_random(2026)
+            st, h = mg.solve(tol=0.0, max_cycles=1)
+            # strips of the iterate instead of 8.6 GB twice: the first and last rows (edge bodies), rows
+            # around the 4 GiB mark of the array (row 16320 of pitch 32784 doubles) and around the middle
+            u = mg.get_solution()
+        n = u.shape[0]
+        rows = np.r_[0:96, 16256:16448, n // 2 - 64:n // 2 + 64, n - 96:n]
+        out[name] = (np.array(h), u[rows].copy(), float(np.abs(u).max()), u[:, ::509].copy())
+        del u
+    assert np.array_equal(out["folded"][1], out["single"][1])
+    assert np.array_equal(out["folded"][3], out["single"][3])
+    assert out["folded"][2] == out["single"][2] and out["folded"][2] > 0
+    assert np.allclose(out["folded"][0], out["single"][0], rtol=1e-13, atol=0)
+    assert out["folded"][0][1] < 0.01 * out["folded"][0][0]          # and the cycle did its work
