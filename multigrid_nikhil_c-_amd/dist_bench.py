@@ -67,14 +67,43 @@ def run(args, emit=None):
         ref = single_gpu_reference(args, L, max(1, min(args.steps, 5)), local)
     dist.barrier()
     transport = None
+    mg = None
+    wire = None
     if backend == "nccl":
-        rccl_id = broadcast_rccl_id()
-        mg = B.Multigrid.rank(rank, world, rccl_id=rccl_id, **cfg)
-        wire = "RCCL send/recv (built-in transport, ncclCommInitRank over xGMI)"
-    else:
+        # the built-in RCCL transport; one warm-up cycle proves every collective it uses before anything
+        # is timed.  If ANY rank fails (never seen on this code, but RCCL with > 1 rank has only ever run
+        # on the driver's node), every rank drops to the host-staged transport and the line says so:
+        # a slower honest number instead of none.
+        err = ""
+        try:
+            rccl_id = broadcast_rccl_id()
+            mg = B.Multigrid.rank(rank, world, rccl_id=rccl_id, **cfg)
+            mg.fill_rhs(1, 0.0)
+            mg.fill_guess_random(12345)
+            mg.solve(tol=0.0, max_cycles=1)
+            mg.synchronize()
+        except Exception as e:      # noqa: BLE001 - whatever it is, the other ranks must hear of it
+            err = f"rank {rank}: {type(e).__name__}: {e}"
+        bad = torch.tensor([1 if err else 0], dtype=torch.int64)
+        dist.all_reduce(bad)
+        if int(bad.item()) == 0:
+            wire = "RCCL send/recv (built-in transport, ncclCommInitRank over xGMI)"
+        else:
+            if err:
+                import sys
+                sys.stderr.write(f"dist_bench: RCCL transport failed ({err}); falling back to host-staged halos\n")
+            if mg is not None:
+                try:
+                    mg.close()
+                except Exception:   # noqa: BLE001
+                    pass
+                mg = None
+            backend = "gloo"
+            wire = f"gloo with host-staged halos (FALLBACK: the RCCL transport failed on {int(bad.item())} rank(s))"
+    if mg is None:
         transport = StagedTransport()
         mg = B.Multigrid.rank(rank, world, transport=transport.struct, **cfg)
-        wire = f"{backend} with host-staged halos (rehearsal transport)"
+        wire = wire or f"{backend} with host-staged halos (rehearsal transport)"
     plan = B.Plan(world, rank, **{k: v for k, v in cfg.items() if k not in ("device", "profile")})
     cut = plan.cut
     halo = plan.level(L).halo
