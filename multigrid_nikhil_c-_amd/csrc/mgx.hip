@@ -380,12 +380,13 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
         const int Q = last ? post : 0;
         const int K = per * parts[p];
         const int R = fuse_rows(s->fuse, l.N, K, sizeof(T) == 8);
+        const int Rc = fuse_rows_auto(s->fuse, l.N, K, sizeof(T) == 8) ? -R : R;      // folded passes: sized by the launcher
         fa.zero_in = (first && zero_in) ? 1 : 0;
         int blocks = 0;
-        if (P && Q == 2) blocks = launch_cycle<T, 1, 2, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
-        else if (P) blocks = launch_cycle<T, 1, 0, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
-        else if (Q == 1) blocks = launch_cycle<T, 0, 1, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
-        else if (Q == 2) blocks = launch_cycle<T, 0, 2, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, R, s->stream);
+        if (P && Q == 2) blocks = launch_cycle<T, 1, 2, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, Rc, s->stream);
+        else if (P) blocks = launch_cycle<T, 1, 0, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, Rc, s->stream);
+        else if (Q == 1) blocks = launch_cycle<T, 0, 1, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, Rc, s->stream);
+        else if (Q == 2) blocks = launch_cycle<T, 0, 2, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, Rc, s->stream);
         else if (!rbgs && K == 1) (void)launch_jacobi<T>(src, b, dst, l.N, l.pitch, 1, l.N, s->cfg.omega, s->rows_per_chunk, s->stream, l.rows);
         else (void)launch_fused<T, SM>(K, src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, 0, R, s->stream, l.rows, fa.zero_in);
         if (Q == 2) *norm_blocks = blocks;
@@ -1549,11 +1550,12 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
                 if (!cycle_k_supported(K, rbgs, sizeof(T) == 8, Q, P)) return MGX_ERR_INVALID;
                 fa.row_lo = lo + f->row0; fa.row_hi = hi + f->row0;
                 int rc;
-                if (P && Q == 2) rc = launch_cycle<T, 1, 2, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, R, st);
-                else if (P && Q == 1) rc = launch_cycle<T, 1, 1, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, R, st);
-                else if (P) rc = launch_cycle<T, 1, 0, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, R, st);
-                else if (Q == 1) rc = launch_cycle<T, 0, 1, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, R, st);
-                else rc = launch_cycle<T, 0, 2, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, R, st);
+                const int Rc = fuse_rows_auto(fc, N, K, sizeof(T) == 8) ? -R : R;
+                if (P && Q == 2) rc = launch_cycle<T, 1, 2, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
+                else if (P && Q == 1) rc = launch_cycle<T, 1, 1, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
+                else if (P) rc = launch_cycle<T, 1, 0, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
+                else if (Q == 1) rc = launch_cycle<T, 0, 1, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
+                else rc = launch_cycle<T, 0, 2, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
                 if (rc < 0) return MGX_ERR_INVALID;
                 if (Q == 2) blocks = rc;
             } else if (!rbgs && K == 1) {

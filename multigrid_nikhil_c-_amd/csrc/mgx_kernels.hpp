@@ -234,6 +234,44 @@ __device__ __forceinline__ Tile wave_tile(int strips, int chunks)
     return t;
 }
 
+// k_jacobi_cycle's map, with SHORTER chunks for the waves that run the edge body.  An edge wave's row
+// step costs ~1.25 x an interior one's (select masks, descriptor offsets), and a pass that is ONE round
+// of workgroups (4096^2, 2048^2, every slab of the multi-GPU driver) ends when its slowest wave does:
+// such passes ran 1.44 us per row step against 1.14 in a seven-round launch.  So the tiles that are
+// certain to be edge tiles - the first and last strip of every chunk row (the grid's first and last
+// columns), and the first and last chunk of every strip - are Re < R rows high:
+//   strips 1 .. S-2: `chunks` chunks, the first Re rows, then R rows each, the last whatever is left (<= Re);
+//   strips 0 and S-1: `chunks_e` chunks of Re rows.
+// Interior tiles first (x fastest, contiguous per XCD as in wave_tile), the two edge strips after them.
+struct CTile { int strip, r0, r1; bool active; };
+__device__ __forceinline__ CTile cycle_tile(int strips, int chunks, int chunks_e, int R, int Re, int row_lo, int row_hi)
+{
+    const int per_xcd = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int nth = blockIdx.x >> 3;
+    const int b = xcd * per_xcd + (xcd >= 4 ? per_xcd - 1 - nth : nth);
+    const long g = (long)b * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int si = strips - 2;
+    const long n_int = si > 0 ? (long)chunks * si : 0;
+    CTile t;
+    if (g < n_int) {
+        const int chunk = (int)(g / si);
+        t.strip = 1 + (int)(g - (long)chunk * si);
+        t.r0 = chunk == 0 ? row_lo : row_lo + Re + (chunk - 1) * R;
+        t.r1 = min(t.r0 + (chunk == 0 ? Re : R), row_hi);
+        t.active = t.r0 < row_hi;
+    } else {
+        const long e = g - n_int;
+        int chunk;
+        if (si > 0) { chunk = (int)(e >> 1); t.strip = (e & 1) ? strips - 1 : 0; }
+        else { chunk = (int)(e / strips); t.strip = (int)(e - (long)chunk * strips); }
+        t.r0 = row_lo + chunk * Re;
+        t.r1 = min(t.r0 + Re, row_hi);
+        t.active = chunk < chunks_e && t.r0 < row_hi;
+    }
+    return t;
+}
+
 struct Cols {           // per-lane column bookkeeping, shared by all kernels
     int vx;             // vector index of this lane in the row
     long col;           // first column of the vector
@@ -1388,8 +1426,8 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
                const T* __restrict__ coarse_e,                       // PRE
                T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,   // POST == 1
                double* __restrict__ partial,                          // POST == 2
-               int N, long pitch, long cpitch, int row_lo, int row_hi, int R, int strips, int chunks, T c0, T c1, int zero_in,
-               CycleWin win)
+               int N, long pitch, long cpitch, int row_lo, int row_hi, int R, int strips, int chunks, int Re, int chunks_e,
+               T c0, T c1, int zero_in, CycleWin win)
 {
     constexpr int W = VecOf<T>::W;
     constexpr int XC = cycle_halo_cols<K, POST>();
@@ -1401,7 +1439,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     // the waves' rhs rings (deep passes only: cycle_b_in_lds)
     constexpr bool BL = cycle_b_in_lds<T, K, POST, SM>();
     __shared__ typename LdsVec<T>::v bring[BL ? kWavesPerBlock * kBRing * kWave : 1];
-    const Tile t = wave_tile(strips, chunks);
+    const CTile t = cycle_tile(strips, chunks, chunks_e, R, Re, row_lo, row_hi);
     double acc = 0.0;
     if (t.active) {
         const int lane = threadIdx.x & 63;
@@ -1412,8 +1450,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         const long col = (long)vx * W;
         const bool ld = (vx >= 0) && (col + W <= pitch);
         const bool st = (lane >= HL) && (lane < kWave - HL) && (vx < N / W);
-        const int r0 = row_lo + t.chunk * R;
-        const int r1 = min(r0 + R, row_hi);
+        const int r0 = t.r0, r1 = t.r1;
         // everything the unpredicated body touches (rows r0-K-ETOP-1 .. r1+K+EBOT+1+kPrefetch:
         // rotation rounding plus the prefetched rows; one vector beyond the first and last lane;
         // the matching coarse rows/columns) strictly inside the grid and inside the window

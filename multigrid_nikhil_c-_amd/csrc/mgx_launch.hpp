@@ -150,6 +150,10 @@ inline int fuse_rows_deep(int N, int rows)
     return 64;
 }
 
+// deep double passes on big grids, height not given by MGX_FUSE_ROWS: launch_cycle_k sizes the chunks itself
+// (edge tiles shorter than interior ones) - it is handed -fuse_rows(...)
+inline bool fuse_rows_auto(const FuseCfg& fc, int N, int K, bool f64) { return fc.rows <= 0 && f64 && K >= 8 && N >= 2048; }
+
 inline int fuse_rows(const FuseCfg& fc, int N, int K, bool f64 = true, int rows = 0)
 {
     if (fc.rows > 0) return fc.rows;
@@ -313,32 +317,72 @@ struct FoldArgs {
     CycleWin win{0, 0, 0, 0, 0, 0};
 };
 
+// chunk geometry of a k_jacobi_cycle launch (cycle_tile in mgx_kernels.hpp): edge tiles Re rows high
+struct CycleGeom { int R, Re, chunks, chunks_e; long waves; };
+inline CycleGeom cycle_geom(int rows, int strips, int R, int Re)
+{
+    CycleGeom g;
+    g.R = R; g.Re = Re;
+    g.chunks_e = (rows + Re - 1) / Re;
+    g.chunks = rows <= Re ? 1 : 2 + std::max(0, (rows - 2 * Re + R - 1) / R);
+    g.waves = strips > 2 ? (long)g.chunks * (strips - 2) + 2L * g.chunks_e : (long)g.chunks_e * strips;
+    return g;
+}
+// height of the edge tiles for interior tiles R rows high: (Re + extra) / (R + extra) ~ 0.77, the inverse
+// of what an edge step costs relative to an interior one, in whole loop trips
+inline int edge_rows(int R, int extra, int trip)
+{
+    const int k = (int)(0.23 * (double)(R + extra) / (double)trip + 0.5);
+    const int Re = R - k * trip;
+    return Re >= trip ? Re : R;
+}
+
+// R < 0: choose the chunk height here (deep double passes: whole rounds of 2048 waves, see fuse_rows_deep;
+// -R is the height the uniform rule gave)
 template <typename T, int K, int PRE, int POST, int SM>
 int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N, long pitch, T c0, T c1, int R,
                    hipStream_t st)
 {
     constexpr int OUT = cycle_out_lanes<K, POST, VecOf<T>::W>();
-    if (R & 1) ++R;                                    // chunks must start on odd rows (POST = 1)
-    {
-        // the interior bodies run whole trips (kBRing steps for the deep variants, kTrip otherwise): a
-        // chunk is R + 2K + (stage rows) steps long, so take the next even R that makes it a multiple
-        // of the trip (or one short of it)
-        constexpr int E = POST == 1 ? 3 : (POST == 2 ? 2 : 0);
-        R = trip_rows(R, 2 * K + E, cycle_b_in_lds<T, K, POST, SM>() ? kBRing : trip_steps<T>(), 2);
-    }
+    constexpr bool BL = cycle_b_in_lds<T, K, POST, SM>();
+    constexpr int E = POST == 1 ? 3 : (POST == 2 ? 2 : 0);
+    constexpr int kTripSteps = BL ? kBRing : trip_steps<T>();
     const bool whole = (fa.row_hi == 0);
     const int row_lo = whole ? 1 : fa.row_lo, row_hi = whole ? N : fa.row_hi;
     const CycleWin win = whole ? CycleWin{0, N, 0, N / 2, 1, N / 2} : fa.win;
-    if (POST == 1 && !(row_lo & 1)) return -1;         // see above
-    Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, R);
-    g.strips = (N / VecOf<T>::W + OUT - 1) / OUT;
-    const long waves = (long)g.strips * g.chunks;
-    g.blocks = (int)(((waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
+    if (POST == 1 && !(row_lo & 1)) return -1;         // chunks must start on odd rows (POST = 1)
+    const int rows = row_hi - row_lo;
+    const int strips = (N / VecOf<T>::W + OUT - 1) / OUT;
+    const bool edge_short = env_int("MGX_EDGE_SHORT", 1) != 0;
+    const bool auto_rows = R < 0;
+    if (auto_rows) R = -R;
+    if (R & 1) ++R;
+    // the bodies run whole trips (kBRing steps for the deep variants, kTrip otherwise): a chunk is
+    // R + 2K + (stage rows) steps long, so take the next even R that makes it a multiple of the trip (or
+    // one short of it)
+    R = trip_rows(R, 2 * K + E, kTripSteps, 2);
+    CycleGeom g = cycle_geom(rows, strips, R, R);
+    if constexpr (BL) {
+        if (auto_rows) {
+            // the fewest rounds of 2048 waves with chunks of at most ~200 rows, and in that many rounds the
+            // shortest chunks that fit
+            bool found = false;
+            for (int m = 1; m <= 64 && !found; ++m) {
+                for (int r = trip_rows(16, 2 * K + E, kTripSteps, 2); r <= 204; r += kTripSteps) {
+                    const CycleGeom c = cycle_geom(rows, strips, r, edge_short ? edge_rows(r, 2 * K + E, kTripSteps) : r);
+                    if (c.waves <= 2048L * m) { g = c; found = true; break; }
+                }
+            }
+        } else if (edge_short) {
+            g = cycle_geom(rows, strips, R, edge_rows(R, 2 * K + E, kTripSteps));
+        }
+    }
+    const int blocks = (int)(((g.waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
-    hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout,
+    hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM>), dim3(blocks), dim3(kBlock), 0, st, vin, b, vout,
                        (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
-                       row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, fa.zero_in, win);
-    return g.blocks;
+                       row_lo, row_hi, g.R, strips, g.chunks, g.Re, g.chunks_e, c0, c1, fa.zero_in, win);
+    return blocks;
 }
 
 template <typename T, int PRE, int POST, int SM>
