@@ -234,15 +234,18 @@ __device__ __forceinline__ Tile wave_tile(int strips, int chunks)
     return t;
 }
 
-// k_jacobi_cycle's map, with SHORTER chunks for the waves that run the edge body.  An edge wave's row
-// step costs ~1.25 x an interior one's (select masks, descriptor offsets), and a pass that is ONE round
-// of workgroups (4096^2, 2048^2, every slab of the multi-GPU driver) ends when its slowest wave does:
-// such passes ran 1.44 us per row step against 1.14 in a seven-round launch.  So the tiles that are
-// certain to be edge tiles - the first and last strip of every chunk row (the grid's first and last
-// columns), and the first and last chunk of every strip - are Re < R rows high:
+// k_jacobi_cycle's map.  A workgroup's four waves are four neighbouring tiles, and a new workgroup starts
+// on a CU only when a wave slot is free on ALL four SIMDs: a workgroup that mixes one slow wave with three
+// fast ones leaves three slots idle until the slow one is done.  The waves of the first and last strip
+// of a chunk row (the grid's first and last columns) always run the edge body, ~1.25 x an interior row
+// step; with the plain map (x fastest) one workgroup in twenty had one.  Here the tiles of strips
+// 1 .. S-2 come first (x fastest, contiguous per XCD as in wave_tile) and the two edge strips after them,
+// so edge waves share workgroups with edge waves: 8192^2 pass 0.479 -> 0.430 ms, 4096^2 0.158 -> 0.146.
+// The edge tiles are also a little SHORTER (Re < R rows: first / last chunk of every strip and all chunks
+// of the two edge strips), so that in a launch of one round of workgroups the slower waves end with the
+// others; measured worth 1-2 % (MGX_EDGE_SHORT=0 makes every tile R rows high):
 //   strips 1 .. S-2: `chunks` chunks, the first Re rows, then R rows each, the last whatever is left (<= Re);
 //   strips 0 and S-1: `chunks_e` chunks of Re rows.
-// Interior tiles first (x fastest, contiguous per XCD as in wave_tile), the two edge strips after them.
 struct CTile { int strip, r0, r1; bool active; };
 __device__ __forceinline__ CTile cycle_tile(int strips, int chunks, int chunks_e, int R, int Re, int row_lo, int row_hi)
 {
