@@ -234,13 +234,14 @@ __device__ __forceinline__ Tile wave_tile(int strips, int chunks)
     return t;
 }
 
-// k_jacobi_cycle's map.  A workgroup's four waves are four neighbouring tiles, and a new workgroup starts
-// on a CU only when a wave slot is free on ALL four SIMDs: a workgroup that mixes one slow wave with three
-// fast ones leaves three slots idle until the slow one is done.  The waves of the first and last strip
-// of a chunk row (the grid's first and last columns) always run the edge body, ~1.25 x an interior row
-// step; with the plain map (x fastest) one workgroup in twenty had one.  Here the tiles of strips
-// 1 .. S-2 come first (x fastest, contiguous per XCD as in wave_tile) and the two edge strips after them,
-// so edge waves share workgroups with edge waves: 8192^2 pass 0.479 -> 0.430 ms, 4096^2 0.158 -> 0.146.
+// k_jacobi_cycle's map.  A workgroup's four waves are four neighbouring tiles.  The waves of the first
+// and last strip of a chunk row (the grid's first and last columns) always run the edge body, ~1.25 x an
+// interior row step; with the plain map (x fastest) one workgroup in twenty had one such wave.  Here the
+// tiles of strips 1 .. S-2 come first (x fastest, contiguous per XCD as in wave_tile) and the two edge
+// strips after them, so edge waves share workgroups with edge waves: 8192^2 pass 0.479 -> 0.430 ms,
+// 4096^2 0.158 -> 0.146, same chunk height, same kernels (A/B inside one GPU call).  Why it pays that much
+// is not established: one-wave workgroups - no workgroup waits for four free wave slots - changed nothing
+// on top of it.
 // The edge tiles are also a little SHORTER (Re < R rows: first / last chunk of every strip and all chunks
 // of the two edge strips), so that in a launch of one round of workgroups the slower waves end with the
 // others; measured worth 1-2 % (MGX_EDGE_SHORT=0 makes every tile R rows high):
