@@ -333,7 +333,7 @@ inline CycleGeom cycle_geom(int rows, int strips, int R, int Re)
 // to 36 % at 8192^2, 4096^2 and 2048^2)
 inline int edge_rows(int R, int extra, int trip)
 {
-    static const double frac = 0.01 * (double)env_int("MGX_EDGE_PCT", 23);
+    const double frac = 0.01 * (double)env_int("MGX_EDGE_PCT", 23);
     const int k = (int)(frac * (double)(R + extra) / (double)trip + 0.5);
     const int Re = R - k * trip;
     return Re >= trip ? Re : R;

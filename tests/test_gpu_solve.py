@@ -458,3 +458,29 @@ def test_arrays_beyond_four_gib_folded_passes_equal_single_sweeps(pkg, monkeypat
     assert out["folded"][2] == out["single"][2] and out["folded"][2] > 0
     assert np.allclose(out["folded"][0], out["single"][0], rtol=1e-13, atol=0)
     assert out["folded"][0][1] < 0.01 * out["folded"][0][0]          # and the cycle did its work
+
+
+def test_chunk_geometry_knobs_of_the_deep_passes_never_change_a_bit(pkg, po, monkeypatch):
+    """the deep folded passes size their tiles in the launcher (whole rounds of waves, shorter edge tiles,
+    edge strips in workgroups of their own): every geometry must give the same bits - uniform tiles,
+    other edge ratios, explicit chunk heights incl. ones that leave a last chunk of a few rows"""
+    cfg = dict(finest_level=11, coarsest_level=8, mu1=10, mu2=10, schedule=0)
+    b = po.rhs_sine(11)
+    u0 = po.fill_uniform(b.shape, 99)
+    keys = ("MGX_EDGE_SHORT", "MGX_EDGE_PCT", "MGX_FUSE_ROWS", "MGX_TILE_MAX_N")
+    ref = None
+    for env in ({}, {"MGX_EDGE_SHORT": "0"}, {"MGX_EDGE_PCT": "40"}, {"MGX_EDGE_PCT": "8"}, {"MGX_FUSE_ROWS": "36"},
+                {"MGX_FUSE_ROWS": "60", "MGX_EDGE_SHORT": "0"}, {"MGX_FUSE_ROWS": "300"}, {"MGX_FUSE_ROWS": "2046"},
+                {"MGX_FUSE_ROWS": "1020", "MGX_EDGE_PCT": "45"}):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("MGX_TILE_MAX_N", "0")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _, h, u = run_gpu(pkg, cfg, b, u0, tol=0.0, max_cycles=2)
+        if ref is None:
+            ref = (u, h)
+            _, h_orc = po.Solver(**cfg).solve(b, u0, tol=0.0, max_cycles=2)
+            assert hist_close(h, h_orc)
+        assert np.array_equal(u, ref[0]), env
+        assert np.allclose(h, ref[1], rtol=1e-13, atol=0), env
