@@ -1694,6 +1694,19 @@ int mgx_rccl_unique_id(void* out128)
     return MGX_OK;
 }
 
+#ifdef MGX_WAVE_TRACE
+// debug build only: the wave trace of the last k_jacobi_cycle launch; returns the number of waves
+__attribute__((visibility("default"))) int mgx_debug_wave_trace(void* out, int cap)
+{
+    int n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(mgx::g_wave_trace_n), sizeof(int)) != hipSuccess) return -1;
+    n = std::min(std::min(n, cap), 1 << 16);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mgx::g_wave_trace), (size_t)n * sizeof(mgx::WaveTrace)) != hipSuccess) return -1;
+    return n;
+}
+#endif
+
 long mgx_dist_exchanges(mgx_handle s) { return (s && s->dist) ? s->dist->exchanges : -1; }
 long mgx_dist_overlapped(mgx_handle s) { return (s && s->dist) ? s->dist->overlapped : -1; }
 

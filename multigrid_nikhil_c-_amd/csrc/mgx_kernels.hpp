@@ -245,10 +245,22 @@ __device__ __forceinline__ Tile wave_tile(int strips, int chunks)
 // The edge tiles are also a little SHORTER (Re < R rows: first / last chunk of every strip and all chunks
 // of the two edge strips), so that in a launch of one round of workgroups the slower waves end with the
 // others; measured worth 1-2 % (MGX_EDGE_SHORT=0 makes every tile R rows high):
-//   strips 1 .. S-2: `chunks` chunks, the first Re rows, then R rows each, the last whatever is left (<= Re);
-//   strips 0 and S-1: `chunks_e` chunks of Re rows.
+//   strips 1 .. S-2: `chunks` chunks: the first Re rows, then R rows each up to row_last0, and the last one
+//                    [row_last0, row_hi) - anchored at the END of the range, Re (+1) rows: the bottom chunk row
+//                    is a boundary row like the top one (the wave trace, tools/wave_trace.py, showed a pass
+//                    of one round ending 30-60 % after its median wave: the full-height last chunk row);
+//   strips 0 and S-1: `chunks_e` chunks of Re rows;
+//   row_last0 = 0: every tile of every strip R = Re rows high, from the top.
+#ifdef MGX_WAVE_TRACE
+// debug build only (make TRACE=1): when every wave of the last k_jacobi_cycle launch started and ended
+// (100 MHz wall clock), where it ran and what it did - read back with mgx_debug_wave_trace
+struct WaveTrace { long long t0, t1; int strip, r0, r1, hw; };
+__device__ WaveTrace g_wave_trace[1 << 16];
+__device__ int g_wave_trace_n;
+#endif
 struct CTile { int strip, r0, r1; bool active; };
-__device__ __forceinline__ CTile cycle_tile(int strips, int chunks, int chunks_e, int R, int Re, int row_lo, int row_hi)
+__device__ __forceinline__ CTile cycle_tile(int strips, int chunks, int chunks_e, int R, int Re, int row_lo, int row_hi,
+                                            int row_last0)
 {
     const int per_xcd = gridDim.x >> 3;
     const int xcd = blockIdx.x & 7;
@@ -261,9 +273,17 @@ __device__ __forceinline__ CTile cycle_tile(int strips, int chunks, int chunks_e
     if (g < n_int) {
         const int chunk = (int)(g / si);
         t.strip = 1 + (int)(g - (long)chunk * si);
-        t.r0 = chunk == 0 ? row_lo : row_lo + Re + (chunk - 1) * R;
-        t.r1 = min(t.r0 + (chunk == 0 ? Re : R), row_hi);
-        t.active = t.r0 < row_hi;
+        if (row_last0 == 0) {
+            t.r0 = row_lo + chunk * R;
+            t.r1 = min(t.r0 + R, row_hi);
+        } else if (chunk == chunks - 1) {
+            t.r0 = row_last0;
+            t.r1 = row_hi;
+        } else {
+            t.r0 = chunk == 0 ? row_lo : row_lo + Re + (chunk - 1) * R;
+            t.r1 = min(t.r0 + (chunk == 0 ? Re : R), row_last0);
+        }
+        t.active = t.r0 < t.r1;
     } else {
         const long e = g - n_int;
         int chunk;
@@ -1431,7 +1451,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
                T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,   // POST == 1
                double* __restrict__ partial,                          // POST == 2
                int N, long pitch, long cpitch, int row_lo, int row_hi, int R, int strips, int chunks, int Re, int chunks_e,
-               T c0, T c1, int zero_in, CycleWin win)
+               int row_last0, T c0, T c1, int zero_in, CycleWin win)
 {
     constexpr int W = VecOf<T>::W;
     constexpr int XC = cycle_halo_cols<K, POST>();
@@ -1443,8 +1463,11 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     // the waves' rhs rings (deep passes only: cycle_b_in_lds)
     constexpr bool BL = cycle_b_in_lds<T, K, POST, SM>();
     __shared__ typename LdsVec<T>::v bring[BL ? kWavesPerBlock * kBRing * kWave : 1];
-    const CTile t = cycle_tile(strips, chunks, chunks_e, R, Re, row_lo, row_hi);
+    const CTile t = cycle_tile(strips, chunks, chunks_e, R, Re, row_lo, row_hi, row_last0);
     double acc = 0.0;
+#ifdef MGX_WAVE_TRACE
+    const long long trace_t0 = wall_clock64();
+#endif
     if (t.active) {
         const int lane = threadIdx.x & 63;
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1496,6 +1519,17 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
                                                         pitch, cpitch, col, N, r0, r1, ld, st, c0, c1, zero_in != 0, win, ring, fo);
         }
     }
+#ifdef MGX_WAVE_TRACE
+    if ((threadIdx.x & 63) == 0) {
+        const int w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+        if (w < (1 << 16)) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            g_wave_trace[w] = WaveTrace{trace_t0, wall_clock64(), t.active ? t.strip : -1, t.r0, t.r1, (int)hw};
+        }
+        if (w == 0) g_wave_trace_n = gridDim.x * kWavesPerBlock;
+    }
+#endif
     if (POST == 2) {
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;

@@ -317,14 +317,24 @@ struct FoldArgs {
     CycleWin win{0, 0, 0, 0, 0, 0};
 };
 
-// chunk geometry of a k_jacobi_cycle launch (cycle_tile in mgx_kernels.hpp): edge tiles Re rows high
-struct CycleGeom { int R, Re, chunks, chunks_e; long waves; };
-inline CycleGeom cycle_geom(int rows, int strips, int R, int Re)
+// chunk geometry of a k_jacobi_cycle launch (cycle_tile in mgx_kernels.hpp)
+struct CycleGeom { int R, Re, chunks, chunks_e, row_last0; long waves; };
+inline CycleGeom cycle_geom(int row_lo, int row_hi, int strips, int R, int Re)
 {
+    const int rows = row_hi - row_lo;
     CycleGeom g;
     g.R = R; g.Re = Re;
     g.chunks_e = (rows + Re - 1) / Re;
-    g.chunks = rows <= Re ? 1 : 2 + std::max(0, (rows - 2 * Re + R - 1) / R);
+    if (Re >= R || rows <= 2 * Re + 2) {
+        // uniform tiles (of the edge height when the range is only a few edge tiles high)
+        g.R = (Re >= R) ? R : Re; g.Re = g.R;
+        g.row_last0 = 0;
+        g.chunks = g.chunks_e = (rows + g.R - 1) / g.R;
+    } else {
+        // first chunk Re rows, last chunk the Re (+1: it must start on a row of row_lo's parity) rows at the end
+        g.row_last0 = row_hi - Re - ((row_hi - Re - row_lo) & 1);
+        g.chunks = 2 + (g.row_last0 - (row_lo + Re) + R - 1) / R;
+    }
     g.waves = strips > 2 ? (long)g.chunks * (strips - 2) + 2L * g.chunks_e : (long)g.chunks_e * strips;
     return g;
 }
@@ -353,7 +363,6 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
     const int row_lo = whole ? 1 : fa.row_lo, row_hi = whole ? N : fa.row_hi;
     const CycleWin win = whole ? CycleWin{0, N, 0, N / 2, 1, N / 2} : fa.win;
     if (POST == 1 && !(row_lo & 1)) return -1;         // chunks must start on odd rows (POST = 1)
-    const int rows = row_hi - row_lo;
     const int strips = (N / VecOf<T>::W + OUT - 1) / OUT;
     const bool edge_short = env_int("MGX_EDGE_SHORT", 1) != 0;
     const bool auto_rows = R < 0;
@@ -363,7 +372,7 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
     // R + 2K + (stage rows) steps long, so take the next even R that makes it a multiple of the trip (or
     // one short of it)
     R = trip_rows(R, 2 * K + E, kTripSteps, 2);
-    CycleGeom g = cycle_geom(rows, strips, R, R);
+    CycleGeom g = cycle_geom(row_lo, row_hi, strips, R, R);
     if constexpr (BL) {
         if (auto_rows) {
             // the fewest rounds of 2048 waves with chunks of at most ~200 rows, and in that many rounds the
@@ -371,19 +380,19 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
             bool found = false;
             for (int m = 1; m <= 64 && !found; ++m) {
                 for (int r = trip_rows(16, 2 * K + E, kTripSteps, 2); r <= 204; r += kTripSteps) {
-                    const CycleGeom c = cycle_geom(rows, strips, r, edge_short ? edge_rows(r, 2 * K + E, kTripSteps) : r);
+                    const CycleGeom c = cycle_geom(row_lo, row_hi, strips, r, edge_short ? edge_rows(r, 2 * K + E, kTripSteps) : r);
                     if (c.waves <= 2048L * m) { g = c; found = true; break; }
                 }
             }
         } else if (edge_short) {
-            g = cycle_geom(rows, strips, R, edge_rows(R, 2 * K + E, kTripSteps));
+            g = cycle_geom(row_lo, row_hi, strips, R, edge_rows(R, 2 * K + E, kTripSteps));
         }
     }
     const int blocks = (int)(((g.waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
     hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM>), dim3(blocks), dim3(kBlock), 0, st, vin, b, vout,
                        (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
-                       row_lo, row_hi, g.R, strips, g.chunks, g.Re, g.chunks_e, c0, c1, fa.zero_in, win);
+                       row_lo, row_hi, g.R, strips, g.chunks, g.Re, g.chunks_e, g.row_last0, c0, c1, fa.zero_in, win);
     return blocks;
 }
 
