@@ -245,10 +245,12 @@ __device__ __forceinline__ Tile wave_tile(int strips, int chunks)
 // The edge tiles are also a little SHORTER (Re < R rows: first / last chunk of every strip and all chunks
 // of the two edge strips), so that in a launch of one round of workgroups the slower waves end with the
 // others; measured worth 1-2 % (MGX_EDGE_SHORT=0 makes every tile R rows high):
-//   strips 1 .. S-2: `chunks` chunks: the first Re rows, then R rows each up to row_last0, and the last one
-//                    [row_last0, row_hi) - anchored at the END of the range, Re (+1) rows: the bottom chunk row
-//                    is a boundary row like the top one (the wave trace, tools/wave_trace.py, showed a pass
-//                    of one round ending 30-60 % after its median wave: the full-height last chunk row);
+//   strips 1 .. S-2: `chunks` chunks: the first Re rows, then R rows each up to row_last0, and the last TWO
+//                    Rl rows each, [row_last0, row_last0 + Rl) and [row_last0 + Rl, row_hi) - anchored at
+//                    the END of the range.  The wave trace (tools/wave_trace.py) showed a pass of one round
+//                    ending 30-60 % after its median wave: the waves whose cone or read-ahead reaches the
+//                    last row (the last chunk row AND the one before it) take 1.35-1.6 us per row step
+//                    against 0.8-1.1 for interior ones, so those two chunk rows are the shortest;
 //   strips 0 and S-1: `chunks_e` chunks of Re rows;
 //   row_last0 = 0: every tile of every strip R = Re rows high, from the top.
 #ifdef MGX_WAVE_TRACE
@@ -260,7 +262,7 @@ __device__ int g_wave_trace_n;
 #endif
 struct CTile { int strip, r0, r1; bool active; };
 __device__ __forceinline__ CTile cycle_tile(int strips, int chunks, int chunks_e, int R, int Re, int row_lo, int row_hi,
-                                            int row_last0)
+                                            int row_last0, int Rl)
 {
     const int per_xcd = gridDim.x >> 3;
     const int xcd = blockIdx.x & 7;
@@ -276,9 +278,9 @@ __device__ __forceinline__ CTile cycle_tile(int strips, int chunks, int chunks_e
         if (row_last0 == 0) {
             t.r0 = row_lo + chunk * R;
             t.r1 = min(t.r0 + R, row_hi);
-        } else if (chunk == chunks - 1) {
-            t.r0 = row_last0;
-            t.r1 = row_hi;
+        } else if (chunk >= chunks - 2) {
+            t.r0 = chunk == chunks - 2 ? row_last0 : row_last0 + Rl;
+            t.r1 = chunk == chunks - 2 ? row_last0 + Rl : row_hi;
         } else {
             t.r0 = chunk == 0 ? row_lo : row_lo + Re + (chunk - 1) * R;
             t.r1 = min(t.r0 + (chunk == 0 ? Re : R), row_last0);
@@ -1190,7 +1192,9 @@ template <bool BL, int POST, bool EDGE = false> constexpr int cycle_pfd() { retu
 // coarse row fetched ONE step ago also waits for every fine row issued before it: with a one-step
 // coarse prefetch the three-row fine prefetch was worth one row.  The interior bodies fetch the
 // coarse rows as far ahead as the fine ones (8 VGPRs per extra row in double).
-template <typename T, bool BL, bool EDGE, int POST> constexpr int cycle_cpfd() { return (BL && !EDGE) ? cycle_pfd<BL, POST>() : 1; }
+// (edge bodies: as deep as their fine rows too, except in the passes without a residual stage - the 10-level
+// one is at 256 registers and would spill)
+template <typename T, bool BL, bool EDGE, int POST> constexpr int cycle_cpfd() { return (BL && !(EDGE && POST == 0)) ? cycle_pfd<BL, POST, EDGE>() : 1; }
 
 // RP: phase of the step inside the kBRing-fold unrolled loop (BL) or inside the 3-fold one (!BL);
 // the window-rotation phase is RP % 3 either way
@@ -1451,7 +1455,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
                T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,   // POST == 1
                double* __restrict__ partial,                          // POST == 2
                int N, long pitch, long cpitch, int row_lo, int row_hi, int R, int strips, int chunks, int Re, int chunks_e,
-               int row_last0, T c0, T c1, int zero_in, CycleWin win)
+               int row_last0, int Rl, T c0, T c1, int zero_in, CycleWin win)
 {
     constexpr int W = VecOf<T>::W;
     constexpr int XC = cycle_halo_cols<K, POST>();
@@ -1463,7 +1467,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     // the waves' rhs rings (deep passes only: cycle_b_in_lds)
     constexpr bool BL = cycle_b_in_lds<T, K, POST, SM>();
     __shared__ typename LdsVec<T>::v bring[BL ? kWavesPerBlock * kBRing * kWave : 1];
-    const CTile t = cycle_tile(strips, chunks, chunks_e, R, Re, row_lo, row_hi, row_last0);
+    const CTile t = cycle_tile(strips, chunks, chunks_e, R, Re, row_lo, row_hi, row_last0, Rl);
     double acc = 0.0;
 #ifdef MGX_WAVE_TRACE
     const long long trace_t0 = wall_clock64();

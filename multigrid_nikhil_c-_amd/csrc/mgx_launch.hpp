@@ -318,22 +318,25 @@ struct FoldArgs {
 };
 
 // chunk geometry of a k_jacobi_cycle launch (cycle_tile in mgx_kernels.hpp)
-struct CycleGeom { int R, Re, chunks, chunks_e, row_last0; long waves; };
-inline CycleGeom cycle_geom(int row_lo, int row_hi, int strips, int R, int Re)
+struct CycleGeom { int R, Re, Rl, chunks, chunks_e, row_last0; long waves; };
+inline CycleGeom cycle_geom(int row_lo, int row_hi, int strips, int R, int Re, int Rl)
 {
     const int rows = row_hi - row_lo;
     CycleGeom g;
-    g.R = R; g.Re = Re;
+    g.R = R; g.Re = Re; g.Rl = Rl;
     g.chunks_e = (rows + Re - 1) / Re;
-    if (Re >= R || rows <= 2 * Re + 2) {
+    if (Re >= R || rows <= Re + 2 * Rl + 2) {
         // uniform tiles (of the edge height when the range is only a few edge tiles high)
-        g.R = (Re >= R) ? R : Re; g.Re = g.R;
+        g.R = (Re >= R) ? R : Re; g.Re = g.R; g.Rl = g.R;
         g.row_last0 = 0;
         g.chunks = g.chunks_e = (rows + g.R - 1) / g.R;
     } else {
-        // first chunk Re rows, last chunk the Re (+1: it must start on a row of row_lo's parity) rows at the end
-        g.row_last0 = row_hi - Re - ((row_hi - Re - row_lo) & 1);
-        g.chunks = 2 + (g.row_last0 - (row_lo + Re) + R - 1) / R;
+        // first chunk Re rows; the last two Rl rows each at the end (the very last one row less when the
+        // parity of the range asks for it: every chunk starts on a row of row_lo's parity, and one row MORE
+        // could cost a whole loop trip)
+        const int last = row_hi - Rl + ((row_hi - Rl - row_lo) & 1);
+        g.row_last0 = last - Rl;
+        g.chunks = 3 + (g.row_last0 - (row_lo + Re) + R - 1) / R;
     }
     g.waves = strips > 2 ? (long)g.chunks * (strips - 2) + 2L * g.chunks_e : (long)g.chunks_e * strips;
     return g;
@@ -341,13 +344,15 @@ inline CycleGeom cycle_geom(int row_lo, int row_hi, int strips, int R, int Re)
 // height of the edge tiles for interior tiles R rows high: (Re + extra) / (R + extra) ~ 0.77, the inverse
 // of what an edge step costs relative to an interior one, in whole loop trips (MGX_EDGE_PCT: flat from 15
 // to 36 % at 8192^2, 4096^2 and 2048^2)
-inline int edge_rows(int R, int extra, int trip)
+inline int edge_rows(int R, int extra, int trip, int pct = -1)
 {
-    const double frac = 0.01 * (double)env_int("MGX_EDGE_PCT", 23);
+    const double frac = 0.01 * (double)(pct >= 0 ? pct : env_int("MGX_EDGE_PCT", 23));
     const int k = (int)(frac * (double)(R + extra) / (double)trip + 0.5);
     const int Re = R - k * trip;
-    return Re >= trip ? Re : R;
+    return Re >= trip ? Re : (R >= 2 * trip ? trip : R);
 }
+// the last two chunk rows (waves that reach the last row of the range: ~1.5 x an interior row step)
+inline int last_rows(int R, int extra, int trip) { return edge_rows(R, extra, trip, env_int("MGX_LAST_PCT", 38)); }
 
 // R < 0: choose the chunk height here (deep double passes: whole rounds of 2048 waves, see fuse_rows_deep;
 // -R is the height the uniform rule gave)
@@ -372,7 +377,7 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
     // R + 2K + (stage rows) steps long, so take the next even R that makes it a multiple of the trip (or
     // one short of it)
     R = trip_rows(R, 2 * K + E, kTripSteps, 2);
-    CycleGeom g = cycle_geom(row_lo, row_hi, strips, R, R);
+    CycleGeom g = cycle_geom(row_lo, row_hi, strips, R, R, R);
     if constexpr (BL) {
         if (auto_rows) {
             // the fewest rounds of 2048 waves with chunks of at most ~200 rows, and in that many rounds the
@@ -380,19 +385,20 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
             bool found = false;
             for (int m = 1; m <= 64 && !found; ++m) {
                 for (int r = trip_rows(16, 2 * K + E, kTripSteps, 2); r <= 204; r += kTripSteps) {
-                    const CycleGeom c = cycle_geom(row_lo, row_hi, strips, r, edge_short ? edge_rows(r, 2 * K + E, kTripSteps) : r);
+                    const CycleGeom c = cycle_geom(row_lo, row_hi, strips, r, edge_short ? edge_rows(r, 2 * K + E, kTripSteps) : r,
+                                                   edge_short ? last_rows(r, 2 * K + E, kTripSteps) : r);
                     if (c.waves <= 2048L * m) { g = c; found = true; break; }
                 }
             }
         } else if (edge_short) {
-            g = cycle_geom(row_lo, row_hi, strips, R, edge_rows(R, 2 * K + E, kTripSteps));
+            g = cycle_geom(row_lo, row_hi, strips, R, edge_rows(R, 2 * K + E, kTripSteps), last_rows(R, 2 * K + E, kTripSteps));
         }
     }
     const int blocks = (int)(((g.waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
     hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM>), dim3(blocks), dim3(kBlock), 0, st, vin, b, vout,
                        (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
-                       row_lo, row_hi, g.R, strips, g.chunks, g.Re, g.chunks_e, g.row_last0, c0, c1, fa.zero_in, win);
+                       row_lo, row_hi, g.R, strips, g.chunks, g.Re, g.chunks_e, g.row_last0, g.Rl, c0, c1, fa.zero_in, win);
     return blocks;
 }
 
