@@ -267,24 +267,56 @@ __device__ __forceinline__ CTile cycle_tile(int strips, int chunks, int chunks_e
     const int per_xcd = gridDim.x >> 3;
     const int xcd = blockIdx.x & 7;
     const int nth = blockIdx.x >> 3;
-    const int b = xcd * per_xcd + (xcd >= 4 ? per_xcd - 1 - nth : nth);
-    const long g = (long)b * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int si = strips - 2;
-    const long n_int = si > 0 ? (long)chunks * si : 0;
     CTile t;
+    if (row_last0 != 0) {
+        // Tiles of two classes (the launcher uses this mode only with >= 3 strips and >= 3 chunks):
+        //   E: the first and the last two chunks of every interior strip, every chunk of the two edge strips -
+        //      waves that (almost certainly) run the edge body;  M: the middle chunks of the interior strips.
+        // EVERY XCD gets an eighth of each class and starts with its E tiles.  With all the E tiles at the
+        // end of one list they all landed on one XCD, two edge workgroups per CU, and ran 1.35-1.6 us per
+        // row step; next to an interior workgroup an edge wave gets the vector ALU whenever its neighbour
+        // waits.
+        const int n_edge = 3 * si + 2 * chunks_e, n_mid = (chunks - 3) * si;
+        const int pe = (n_edge + 7) >> 3, pm = (n_mid + 7) >> 3;
+        const int lw = nth * kWavesPerBlock + wave;
+        if (lw < pe) {
+            const int e = xcd * pe + lw;
+            t.active = e < n_edge;
+            if (e < 3 * si) {
+                const int which = e / si;                                 // 0: first chunk, 1 / 2: the last two
+                t.strip = 1 + (e - which * si);
+                t.r0 = which == 0 ? row_lo : (which == 1 ? row_last0 : row_last0 + Rl);
+                t.r1 = which == 0 ? row_lo + Re : (which == 1 ? row_last0 + Rl : row_hi);
+            } else {
+                const int k = e - 3 * si;
+                const int chunk = k >> 1;
+                t.strip = (k & 1) ? strips - 1 : 0;
+                t.r0 = row_lo + chunk * Re;
+                t.r1 = min(t.r0 + Re, row_hi);
+            }
+        } else {
+            const int m = xcd * pm + (lw - pe);
+            const int chunk = 1 + m / si;
+            t.active = (lw - pe) < pm && m < n_mid;
+            t.strip = 1 + (m - (chunk - 1) * si);
+            t.r0 = row_lo + Re + (chunk - 1) * R;
+            t.r1 = min(t.r0 + R, row_last0);
+        }
+        t.active = t.active && t.r0 < t.r1;
+        return t;
+    }
+    // uniform tiles: interior strips first (x fastest, a contiguous range per XCD, the upper four XCDs walking
+    // theirs backwards), then the two edge strips
+    const int b = xcd * per_xcd + (xcd >= 4 ? per_xcd - 1 - nth : nth);
+    const long g = (long)b * kWavesPerBlock + wave;
+    const long n_int = si > 0 ? (long)chunks * si : 0;
     if (g < n_int) {
         const int chunk = (int)(g / si);
         t.strip = 1 + (int)(g - (long)chunk * si);
-        if (row_last0 == 0) {
-            t.r0 = row_lo + chunk * R;
-            t.r1 = min(t.r0 + R, row_hi);
-        } else if (chunk >= chunks - 2) {
-            t.r0 = chunk == chunks - 2 ? row_last0 : row_last0 + Rl;
-            t.r1 = chunk == chunks - 2 ? row_last0 + Rl : row_hi;
-        } else {
-            t.r0 = chunk == 0 ? row_lo : row_lo + Re + (chunk - 1) * R;
-            t.r1 = min(t.r0 + (chunk == 0 ? Re : R), row_last0);
-        }
+        t.r0 = row_lo + chunk * R;
+        t.r1 = min(t.r0 + R, row_hi);
         t.active = t.r0 < t.r1;
     } else {
         const long e = g - n_int;

@@ -325,7 +325,7 @@ inline CycleGeom cycle_geom(int row_lo, int row_hi, int strips, int R, int Re, i
     CycleGeom g;
     g.R = R; g.Re = Re; g.Rl = Rl;
     g.chunks_e = (rows + Re - 1) / Re;
-    if (Re >= R || rows <= Re + 2 * Rl + 2) {
+    if (Re >= R || rows <= Re + 2 * Rl + 2 || strips < 3) {
         // uniform tiles (of the edge height when the range is only a few edge tiles high)
         g.R = (Re >= R) ? R : Re; g.Re = g.R; g.Rl = g.R;
         g.row_last0 = 0;
@@ -394,7 +394,13 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
             g = cycle_geom(row_lo, row_hi, strips, R, edge_rows(R, 2 * K + E, kTripSteps), last_rows(R, 2 * K + E, kTripSteps));
         }
     }
-    const int blocks = (int)(((g.waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
+    int blocks = (int)(((g.waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
+    if (g.row_last0 != 0) {
+        // two tile classes, an eighth of each per XCD (cycle_tile)
+        const int si = strips - 2;
+        const int pe = (3 * si + 2 * g.chunks_e + 7) / 8, pm = ((g.chunks - 3) * si + 7) / 8;
+        blocks = 8 * ((pe + pm + kWavesPerBlock - 1) / kWavesPerBlock);
+    }
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
     hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM>), dim3(blocks), dim3(kBlock), 0, st, vin, b, vout,
                        (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
