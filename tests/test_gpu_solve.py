@@ -467,11 +467,12 @@ def test_chunk_geometry_knobs_of_the_deep_passes_never_change_a_bit(pkg, po, mon
     cfg = dict(finest_level=11, coarsest_level=8, mu1=10, mu2=10, schedule=0)
     b = po.rhs_sine(11)
     u0 = po.fill_uniform(b.shape, 99)
-    keys = ("MGX_EDGE_SHORT", "MGX_EDGE_PCT", "MGX_FUSE_ROWS", "MGX_TILE_MAX_N")
+    keys = ("MGX_EDGE_SHORT", "MGX_EDGE_PCT", "MGX_LAST_PCT", "MGX_FUSE_ROWS", "MGX_TILE_MAX_N")
     ref = None
     for env in ({}, {"MGX_EDGE_SHORT": "0"}, {"MGX_EDGE_PCT": "40"}, {"MGX_EDGE_PCT": "8"}, {"MGX_FUSE_ROWS": "36"},
                 {"MGX_FUSE_ROWS": "60", "MGX_EDGE_SHORT": "0"}, {"MGX_FUSE_ROWS": "300"}, {"MGX_FUSE_ROWS": "2046"},
-                {"MGX_FUSE_ROWS": "1020", "MGX_EDGE_PCT": "45"}):
+                {"MGX_FUSE_ROWS": "1020", "MGX_EDGE_PCT": "45"}, {"MGX_LAST_PCT": "5"}, {"MGX_LAST_PCT": "70", "MGX_EDGE_PCT": "0"},
+                {"MGX_FUSE_ROWS": "96", "MGX_LAST_PCT": "50"}):
         for k in keys:
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("MGX_TILE_MAX_N", "0")
