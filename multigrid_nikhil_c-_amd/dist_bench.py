@@ -66,6 +66,15 @@ def run(args, emit=None):
     if rank == 0:
         ref = single_gpu_reference(args, L, max(1, min(args.steps, 5)), local)
     dist.barrier()
+    if rehearsal:
+        # every rank on ONE device: each loads the code object and runs its first kernel alone (a rank's very
+        # first launch once died with an illegal-instruction fault while the others were doing the same)
+        for r in range(world):
+            if r == rank:
+                with B.Multigrid(finest_level=6, coarsest_level=5, schedule=B.SCHEDULE_V, device=local) as warm:
+                    warm.fill_rhs(1, 0.0)
+                    warm.synchronize()
+            dist.barrier()
     transport = None
     mg = None
     wire = None

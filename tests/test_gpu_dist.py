@@ -198,6 +198,15 @@ def _worker(rank, world, port, c, ret):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        # the ranks share ONE GPU here: let each load the library's code object and run its first kernel alone
+        # (once, a rank's very first launch - a fill kernel - died with an illegal-instruction fault while the
+        # other ranks were doing the same; one process per GPU, the real configuration, has no such moment)
+        for r in range(world):
+            if r == rank:
+                with pkg.Multigrid(finest_level=6, coarsest_level=5, schedule=0, device=0) as warm:
+                    warm.fill_rhs(1, 0.0)
+                    warm.synchronize()
+            dist.barrier()
         tr = StagedTransport()
         b, u0 = _problem(po, c)
         with pkg.Multigrid.rank(rank, world, transport=tr.struct, cut_level=c["cut"], device=0, **_cfg(pkg, c)) as mg:
