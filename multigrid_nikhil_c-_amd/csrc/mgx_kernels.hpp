@@ -1559,9 +1559,12 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     if ((threadIdx.x & 63) == 0) {
         const int w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
         if (w < (1 << 16)) {
-            unsigned hw;
+            unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-            g_wave_trace[w] = WaveTrace{trace_t0, wall_clock64(), t.active ? t.strip : -1, t.r0, t.r1, (int)hw};
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            // (HW_ID bits 16-19, the workgroup id within the CU, are not used by tools/wave_trace.py: the XCC id goes there)
+            g_wave_trace[w] = WaveTrace{trace_t0, wall_clock64(), t.active ? t.strip : -1, t.r0, t.r1,
+                                        (int)((hw & 0xFFF0FFFFu) | ((xcc & 0xFu) << 16))};
         }
         if (w == 0) g_wave_trace_n = gridDim.x * kWavesPerBlock;
     }

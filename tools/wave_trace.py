@@ -51,3 +51,32 @@ for i in range(0, 10):
     print(f"  start decile {i}: start {start[sel].mean():7.1f}  dur {dur[sel].mean():7.1f}  end {end[sel].mean():7.1f}")
 late = np.argsort(end)[-12:]
 print("  last waves to end: " + ", ".join(f"(strip {act[i, 2]}, rows {act[i, 3]}..{act[i, 4]}, start {start[i]:.0f}, dur {dur[i]:.0f})" for i in late))
+
+# ---- where did the slow waves run?  HW_ID (gfx9): wave_id[3:0] simd_id[5:4] pipe_id[7:6] cu_id[11:8] sh_id[12] se_id[15:13]
+hw = act[:, 5]
+simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
+key = (se * 2 + sh) * 16 + cu            # CU within its XCD (the XCC id is in another register)
+first = start < 5.0                      # first-round waves
+import collections
+per_cu = collections.defaultdict(list)
+for k, sm, d0, f in zip(key, simd, dur, first):
+    if f:
+        per_cu[(int(k), int(sm))].append(d0)
+n_on_simd = np.array([len(v) for v in per_cu.values()])
+mean_on_simd = np.array([np.mean(v) for v in per_cu.values()])
+print(f"  first-round waves per (CU-in-XCD, SIMD) slot group (8 XCDs share each key): counts {np.bincount(n_on_simd)[:24]}")
+q = np.argsort(dur[first])
+d1 = dur[first]
+print(f"  first-round duration deciles: {np.percentile(d1, [0, 10, 25, 50, 75, 90, 100]).round(1)}")
+for name, arr in (("simd", simd), ("se", se), ("cu", cu)):
+    vals = [f"{v}:{np.median(dur[first & (arr == v)]):.0f}" for v in np.unique(arr)]
+    print(f"  median first-round duration by {name}: " + " ".join(vals))
+xcc = (hw >> 16) & 15
+print("  first-round duration by XCC (median / max / waves): " +
+      " ".join(f"{v}:{np.median(dur[first & (xcc == v)]):.0f}/{dur[first & (xcc == v)].max():.0f}/{(first & (xcc == v)).sum()}" for v in np.unique(xcc)))
+print("  waves per SIMD by XCC (min..max over its SIMDs): " +
+      " ".join(f"{v}:{np.bincount((key * 4 + simd)[first & (xcc == v)]).min()}..{np.bincount((key * 4 + simd)[first & (xcc == v)]).max()}" for v in np.unique(xcc)))
+# by tile position
+r0s = act[:, 3]
+print("  median first-round duration by chunk row (first 12 / last 6): " +
+      " ".join(f"{int(r)}:{np.median(dur[first & (r0s == r)]):.0f}" for r in list(np.unique(r0s[first]))[:12] + list(np.unique(r0s[first]))[-6:]))
