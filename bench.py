@@ -64,6 +64,9 @@ def parse():
     p.add_argument("--omega", type=float, default=2.0 / 3.0, help="Jacobi weight (PS:127)")
     p.add_argument("--smoother", choices=["jacobi", "rbgs"], default="jacobi")
     p.add_argument("--dtype", choices=["f64", "f32", "mixed"], default="f64")
+    p.add_argument("--arith", choices=["fma", "separate"], default="fma",
+                   help="rounding of the Jacobi update (mgx_config.arith): fma = v' = fma(c1, nb, fma(c0, v, c1 b)), "
+                        "separate = the reference's five library calls as five roundings (PS:138-142)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-level", type=int, default=13, help="grid level of the bounded CPU-baseline sample")
     return p.parse_args()
@@ -158,7 +161,7 @@ def run_single(args):
     n = (1 << L) - 1
     cfg = dict(finest_level=L, coarsest_level=min(args.coarsest, L), mu0=0, mu1=args.mu1, mu2=args.mu2,
                omega=args.omega, smoother=1 if args.smoother == "rbgs" else 0, dtype=DT[args.dtype],
-               schedule=pkg.SCHEDULE_V, profile=2)
+               schedule=pkg.SCHEDULE_V, profile=2, arith=pkg.ARITH_FMA if args.arith == "fma" else pkg.ARITH_SEPARATE)
     # profile = 2: the finest level's passes are launched one by one between HIP events, the rest of the
     # cycle is one hipGraph replay between two events (include/mgx.h) - mgx_solve's own execution, timed
     mg = pkg.Multigrid(**cfg)

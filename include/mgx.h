@@ -47,6 +47,15 @@ enum { MGX_DTYPE_F32 = 0, MGX_DTYPE_F64 = 1, MGX_DTYPE_MIXED = 2 };
 enum { MGX_SCHEDULE_V = 0, MGX_SCHEDULE_FMG = 1 };
 enum { MGX_RESTRICT_CONSISTENT = 0, MGX_RESTRICT_FW16 = 1 };
 enum { MGX_BOTTOM_EXACT = 0, MGX_BOTTOM_SMOOTH = 1 };
+/* Arithmetic of the weighted-Jacobi update  v' = (1-w) v + (w/4) b + (w/4)(N+W+E+S)  (PS:138-142):
+ *   SEPARATE: the reference's five library calls as five roundings per point, in its order
+ *             (t = c0 v + c1 b ; v' = t + c1 nb) - bit-identical to the CPU oracle's default mode;
+ *   FMA:      the same expression with its two multiply-adds contracted, v' = fma(c1, nb, fma(c0, v, c1 b)):
+ *             what oneMKL's fused kernels would be free to do; two roundings fewer per point, bit-identical
+ *             to the oracle's FMA mode and within 1e-10 of the SEPARATE residual histories (north_star's
+ *             tolerance; tests/test_gpu_fma.py).  Every other operator (residual, transfers, red-black
+ *             Gauss-Seidel, bottom solve) performs the same operations in both modes. */
+enum { MGX_ARITH_SEPARATE = 0, MGX_ARITH_FMA = 1 };
 #define MGX_MAX_GPUS 16
 
 /* The reference's compile-time globals as run-time fields.
@@ -81,6 +90,7 @@ typedef struct {
     int n_gpus;           /* 0 or 1: single GPU */
     int cut_level;        /* 0: chosen from the grid and n_gpus */
     int devices[MGX_MAX_GPUS];   /* -1 entries: slab g on device g modulo the device count */
+    int arith;            /* MGX_ARITH_*     (PS:138-142: how the Jacobi update is rounded) */
 } mgx_config;
 
 typedef struct mgx_solver* mgx_handle;
@@ -236,6 +246,7 @@ typedef struct {
     int dtype;        /* MGX_DTYPE_F32 / MGX_DTYPE_F64 */
     int rows;         /* rows allocated in the slab */
     int row0;         /* global row index of local row 0 */
+    int arith;        /* MGX_ARITH_* of the smoother calls (mgx_config.arith) */
 } mgx_slab;
 
 /* elements per row for (level, dtype); bytes per row = pitch * sizeof(type) */

@@ -25,6 +25,7 @@ DTYPE_F32, DTYPE_F64, DTYPE_MIXED = 0, 1, 2
 SCHEDULE_V, SCHEDULE_FMG = 0, 1
 RESTRICT_CONSISTENT, RESTRICT_FW16 = 0, 1
 BOTTOM_EXACT, BOTTOM_SMOOTH = 0, 1
+ARITH_SEPARATE, ARITH_FMA = 0, 1
 VEC_U, VEC_B, VEC_R = 0, 1, 2
 PROF_SMOOTH_FINE, PROF_RESTRICT_FINE, PROF_PROLONG_FINE, PROF_NORM_FINE, PROF_COARSE, PROF_COUNT = 0, 1, 2, 3, 4, 5
 
@@ -56,6 +57,7 @@ class Config(C.Structure):
         ("restrict_mode", C.c_int), ("bottom", C.c_int),
         ("device", C.c_int), ("profile", C.c_int),
         ("n_gpus", C.c_int), ("cut_level", C.c_int), ("devices", C.c_int * MAX_GPUS),
+        ("arith", C.c_int),
     ]
 
 
@@ -73,7 +75,7 @@ class Profile(C.Structure):
 
 
 class Slab(C.Structure):
-    _fields_ = [("level", C.c_int), ("dtype", C.c_int), ("rows", C.c_int), ("row0", C.c_int)]
+    _fields_ = [("level", C.c_int), ("dtype", C.c_int), ("rows", C.c_int), ("row0", C.c_int), ("arith", C.c_int)]
 
 
 class DistOp(C.Structure):

@@ -241,8 +241,10 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
     if (tile_level(s, l)) {
         FoldArgs fa;
         const int rc = s->cfg.smoother == MGX_SMOOTHER_RBGS
-            ? smooth_tiled<T, 1>((T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, mu, s->cfg.omega, s->fuse.tile_k, fa, false, 0, false, s->stream, &launches)
-            : smooth_tiled<T, 0>((T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, mu, s->cfg.omega, s->fuse.tile_k, fa, false, 0, false, s->stream, &launches);
+            ? smooth_tiled<T, 1, 0>((T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, mu, s->cfg.omega, s->fuse.tile_k, fa, false, 0, false, s->stream, &launches)
+            : (s->fuse.arith
+               ? smooth_tiled<T, 0, 1>((T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, mu, s->cfg.omega, s->fuse.tile_k, fa, false, 0, false, s->stream, &launches)
+               : smooth_tiled<T, 0, 0>((T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, mu, s->cfg.omega, s->fuse.tile_k, fa, false, 0, false, s->stream, &launches));
         if (rc >= 0) {
             s->last_smooth_launches = launches;
             if (launches & 1) std::swap(l.u, l.tmp);
@@ -343,7 +345,7 @@ int fold_plan(const mgx_solver* s, const Level& l, int mu, bool pre, int post, i
 // Returns false when this level / configuration is not eligible (caller then
 // uses the stand-alone kernels); on success *norm_blocks = partial sums written.
 
-template <typename T, int SM>
+template <typename T, int SM, int AR>
 bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool pre, int post, int* launches,
                      int* norm_blocks, bool zero_in)
 {
@@ -359,7 +361,7 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
     }
     if (tile_level(s, l)) {
         int flips = 0;
-        const int nb = smooth_tiled<T, SM>((T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, mu, s->cfg.omega,
+        const int nb = smooth_tiled<T, SM, AR>((T*)l.u, (const T*)l.b, (T*)l.tmp, l.N, l.pitch, mu, s->cfg.omega,
                                            s->fuse.tile_k, fa, pre, post, zero_in, s->stream, &flips);
         if (nb < 0) return false;
         if (flips & 1) std::swap(l.u, l.tmp);
@@ -383,12 +385,12 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
         const int Rc = fuse_rows_auto(s->fuse, l.N, K, sizeof(T) == 8) ? -R : R;      // folded passes: sized by the launcher
         fa.zero_in = (first && zero_in) ? 1 : 0;
         int blocks = 0;
-        if (P && Q == 2) blocks = launch_cycle<T, 1, 2, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, Rc, s->stream);
-        else if (P) blocks = launch_cycle<T, 1, 0, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, Rc, s->stream);
-        else if (Q == 1) blocks = launch_cycle<T, 0, 1, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, Rc, s->stream);
-        else if (Q == 2) blocks = launch_cycle<T, 0, 2, SM>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, Rc, s->stream);
-        else if (!rbgs && K == 1) (void)launch_jacobi<T>(src, b, dst, l.N, l.pitch, 1, l.N, s->cfg.omega, s->rows_per_chunk, s->stream, l.rows);
-        else (void)launch_fused<T, SM>(K, src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, 0, R, s->stream, l.rows, fa.zero_in);
+        if (P && Q == 2) blocks = launch_cycle<T, 1, 2, SM, AR>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, Rc, s->stream);
+        else if (P) blocks = launch_cycle<T, 1, 0, SM, AR>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, Rc, s->stream);
+        else if (Q == 1) blocks = launch_cycle<T, 0, 1, SM, AR>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, Rc, s->stream);
+        else if (Q == 2) blocks = launch_cycle<T, 0, 2, SM, AR>(K, src, b, dst, fa, l.N, l.pitch, c0, c1, Rc, s->stream);
+        else if (!rbgs && K == 1) (void)launch_jacobi<T>(src, b, dst, l.N, l.pitch, 1, l.N, s->cfg.omega, s->rows_per_chunk, s->stream, l.rows, AR);
+        else (void)launch_fused<T, SM, AR>(K, src, b, dst, l.N, l.pitch, 1, l.N, c0, c1, 0, l.N, 0, R, s->stream, l.rows, fa.zero_in);
         if (Q == 2) *norm_blocks = blocks;
         std::swap(src, dst);
     }
@@ -440,10 +442,13 @@ bool smooth_folded(mgx_solver* s, int level, int mu, bool pre, int post, bool ze
     int launches = 0, nb = 0;
     const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
     bool ok;
-    if (l.f64) ok = rbgs ? smooth_folded_t<double, 1>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
-                         : smooth_folded_t<double, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in);
-    else ok = rbgs ? smooth_folded_t<float, 1>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
-                   : smooth_folded_t<float, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in);
+    const bool fma = s->fuse.arith != 0;
+    if (l.f64) ok = rbgs ? smooth_folded_t<double, 1, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
+                         : (fma ? smooth_folded_t<double, 0, 1>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
+                                : smooth_folded_t<double, 0, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in));
+    else ok = rbgs ? smooth_folded_t<float, 1, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
+                   : (fma ? smooth_folded_t<float, 0, 1>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
+                          : smooth_folded_t<float, 0, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in));
     if (!ok) return false;
     p.set(launches, mu);
     if (post == 2) s->norm_blocks_ready = nb;
@@ -848,6 +853,7 @@ int mgx_config_default(mgx_config* c)
     c->n_gpus = 0;             // PS:659: one queue
     c->cut_level = 0;
     for (int i = 0; i < MGX_MAX_GPUS; ++i) c->devices[i] = -1;
+    c->arith = MGX_ARITH_SEPARATE;
     return MGX_OK;
 }
 
@@ -884,7 +890,7 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
         cfg->mu0 < 0 || cfg->mu1 < 0 || cfg->mu2 < 0 || !(cfg->omega > 0.0 && cfg->omega < 2.0) ||
         cfg->smoother < 0 || cfg->smoother > 1 || cfg->dtype < 0 || cfg->dtype > 2 ||
         cfg->schedule < 0 || cfg->schedule > 1 || cfg->restrict_mode < 0 || cfg->restrict_mode > 1 ||
-        cfg->bottom < 0 || cfg->bottom > 1) {
+        cfg->bottom < 0 || cfg->bottom > 1 || cfg->arith < 0 || cfg->arith > 1) {
         g_create_error = "invalid configuration";
         return MGX_ERR_INVALID;
     }
@@ -907,6 +913,7 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
     s->work_f64 = (cfg->dtype == MGX_DTYPE_F64);
     s->rows_per_chunk = env_int("MGX_ROWS", 0);
     s->fuse = fuse_cfg();
+    s->fuse.arith = cfg->arith;
     s->fold = env_int("MGX_FOLD", 1);
     s->use_zero_in = env_int("MGX_ZERO_IN", 1);
     s->use_graph = env_int("MGX_GRAPH", 1);
@@ -1437,6 +1444,7 @@ static int slab_check(const mgx_slab* s)
 {
     if (!s || s->level < 2 || s->level > 15 || s->rows < 1) return MGX_ERR_INVALID;
     if (s->dtype != MGX_DTYPE_F32 && s->dtype != MGX_DTYPE_F64) return MGX_ERR_INVALID;
+    if (s->arith != MGX_ARITH_SEPARATE && s->arith != MGX_ARITH_FMA) return MGX_ERR_INVALID;
     // the slab must lie inside the grid: rows row0 .. row0 + rows - 1 of rows 0 .. N
     if (s->row0 < 0 || s->row0 + s->rows > (1 << s->level) + 1) return MGX_ERR_INVALID;
     return MGX_OK;
@@ -1463,7 +1471,8 @@ static int slab_smooth(int smoother, const mgx_slab* s, void* u, const void* b, 
     const long pitch = level_pitch(s->level, s->dtype);
     const int first = 1 - s->row0, last = N - s->row0;      // unknown rows are [first, last)
     const int rpc = env_int("MGX_ROWS", 0);
-    const FuseCfg fc = fuse_cfg();
+    FuseCfg fc = fuse_cfg();
+    fc.arith = s->arith;
     int parity = 0, rc;
     if (s->dtype == MGX_DTYPE_F64)
         rc = smooth_block<double>(smoother, (double*)u, (const double*)b, (double*)tmp, N, pitch, s->rows, row_lo, row_hi,
@@ -1493,7 +1502,7 @@ int mgx_slab_rbgs(const mgx_slab* s, void* u, const void* b, void* tmp, int row_
 namespace {
 // mu sweeps on a slab with the cycle's transfers folded into the passes (k_jacobi_cycle on the
 // window of rows the slab holds).  Local row numbers in, global ones to the kernel.
-template <typename T, int SM>
+template <typename T, int SM, int AR>
 int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int row_hi, int mu, double omega,
                         const mgx_slab* c, const T* coarse_e, T* coarse_b, int crow_lo, int crow_hi, int restrict_mode,
                         double* scratch, double* sum_dev, int* result_in_tmp, hipStream_t st)
@@ -1504,6 +1513,7 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
     const long pitch = level_pitch(f->level, f->dtype);
     const int first = 1 - f->row0, last = N - f->row0;        // local unknown rows [first, last)
     FuseCfg fc = fuse_cfg();
+    fc.arith = AR;
     const int post = coarse_b ? 1 : (sum_dev ? 2 : 0);
     if (coarse_e && coarse_b) {                  // correction and restriction may meet in one pass: at most 8 levels
         fc.fold_kmax = std::min(fc.fold_kmax, 8); fc.fold_kmax_big = std::min(fc.fold_kmax_big, 8);
@@ -1551,16 +1561,16 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
                 fa.row_lo = lo + f->row0; fa.row_hi = hi + f->row0;
                 int rc;
                 const int Rc = fuse_rows_auto(fc, N, K, sizeof(T) == 8) ? -R : R;
-                if (P && Q == 2) rc = launch_cycle<T, 1, 2, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
-                else if (P && Q == 1) rc = launch_cycle<T, 1, 1, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
-                else if (P) rc = launch_cycle<T, 1, 0, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
-                else if (Q == 1) rc = launch_cycle<T, 0, 1, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
-                else rc = launch_cycle<T, 0, 2, SM>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
+                if (P && Q == 2) rc = launch_cycle<T, 1, 2, SM, AR>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
+                else if (P && Q == 1) rc = launch_cycle<T, 1, 1, SM, AR>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
+                else if (P) rc = launch_cycle<T, 1, 0, SM, AR>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
+                else if (Q == 1) rc = launch_cycle<T, 0, 1, SM, AR>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
+                else rc = launch_cycle<T, 0, 2, SM, AR>(K, src - back, b - back, dst - back, fa, N, pitch, c0, c1, Rc, st);
                 if (rc < 0) return MGX_ERR_INVALID;
                 if (Q == 2) blocks = rc;
             } else if (!rbgs && K == 1) {
-                if (launch_jacobi<T>(src, b, dst, N, pitch, lo, hi, omega, env_int("MGX_ROWS", 0), st, f->rows)) return MGX_ERR_INVALID;
-            } else if (!launch_fused<T, SM>(K, src, b, dst, N, pitch, lo, hi, c0, c1, first - 1, last, f->row0 & 1, R, st, f->rows)) {
+                if (launch_jacobi<T>(src, b, dst, N, pitch, lo, hi, omega, env_int("MGX_ROWS", 0), st, f->rows, AR)) return MGX_ERR_INVALID;
+            } else if (!launch_fused<T, SM, AR>(K, src, b, dst, N, pitch, lo, hi, c0, c1, first - 1, last, f->row0 & 1, R, st, f->rows, 0)) {
                 return MGX_ERR_INVALID;
             }
         }
@@ -1589,19 +1599,14 @@ int mgx_slab_cycle(const mgx_slab* f, void* u, const void* b, void* tmp, int row
     if (row_lo < 0 || row_hi > f->rows || row_lo + f->row0 < 1 || row_hi + f->row0 > N) return MGX_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const bool rbgs = (smoother == MGX_SMOOTHER_RBGS);
+#define MGX_SLAB_CYCLE(T, SM, AR)                                                                                       \
+    slab_cycle_t<T, SM, AR>(f, (T*)u, (const T*)b, (T*)tmp, row_lo, row_hi, mu, omega, c, (const T*)coarse_e, (T*)coarse_b, \
+                            crow_lo, crow_hi, restrict_mode, scratch, sum_dev, result_in_tmp, st)
+    const bool fma = f->arith == MGX_ARITH_FMA;
     if (f->dtype == MGX_DTYPE_F64)
-        return rbgs ? slab_cycle_t<double, 1>(f, (double*)u, (const double*)b, (double*)tmp, row_lo, row_hi, mu, omega, c,
-                                              (const double*)coarse_e, (double*)coarse_b, crow_lo, crow_hi, restrict_mode,
-                                              scratch, sum_dev, result_in_tmp, st)
-                    : slab_cycle_t<double, 0>(f, (double*)u, (const double*)b, (double*)tmp, row_lo, row_hi, mu, omega, c,
-                                              (const double*)coarse_e, (double*)coarse_b, crow_lo, crow_hi, restrict_mode,
-                                              scratch, sum_dev, result_in_tmp, st);
-    return rbgs ? slab_cycle_t<float, 1>(f, (float*)u, (const float*)b, (float*)tmp, row_lo, row_hi, mu, omega, c,
-                                         (const float*)coarse_e, (float*)coarse_b, crow_lo, crow_hi, restrict_mode, scratch,
-                                         sum_dev, result_in_tmp, st)
-                : slab_cycle_t<float, 0>(f, (float*)u, (const float*)b, (float*)tmp, row_lo, row_hi, mu, omega, c,
-                                         (const float*)coarse_e, (float*)coarse_b, crow_lo, crow_hi, restrict_mode, scratch,
-                                         sum_dev, result_in_tmp, st);
+        return rbgs ? MGX_SLAB_CYCLE(double, 1, 0) : (fma ? MGX_SLAB_CYCLE(double, 0, 1) : MGX_SLAB_CYCLE(double, 0, 0));
+    return rbgs ? MGX_SLAB_CYCLE(float, 1, 0) : (fma ? MGX_SLAB_CYCLE(float, 0, 1) : MGX_SLAB_CYCLE(float, 0, 0));
+#undef MGX_SLAB_CYCLE
 }
 
 int mgx_slab_restrict(const mgx_slab* f, const void* u, const void* b, const mgx_slab* c, void* cb, void* zero_u,
@@ -1670,7 +1675,7 @@ int mgx_create_rank(const mgx_config* cfg, int rank, int world, const void* rccl
     *out = nullptr;
     if (cfg->coarsest_level < 2 || cfg->finest_level < cfg->coarsest_level || cfg->finest_level > 15 ||
         cfg->mu1 < 0 || cfg->mu2 < 0 || !(cfg->omega > 0.0 && cfg->omega < 2.0) || cfg->smoother < 0 || cfg->smoother > 1 ||
-        cfg->dtype < 0 || cfg->dtype > 2 || cfg->restrict_mode < 0 || cfg->restrict_mode > 1 || cfg->bottom < 0 || cfg->bottom > 1 ||
+        cfg->dtype < 0 || cfg->dtype > 2 || cfg->restrict_mode < 0 || cfg->restrict_mode > 1 || cfg->bottom < 0 || cfg->bottom > 1 || cfg->arith < 0 || cfg->arith > 1 ||
         (rank >= 0 && (world < 1 || rank >= world)) || (rank < 0 && cfg->n_gpus < 2)) {
         g_create_error = "invalid configuration";
         return MGX_ERR_INVALID;

@@ -177,7 +177,7 @@ int dist_alloc_slab(mgx_solver* s, mgx_dist* d, DistSlab& sl)
             DCHK(s, hipMemsetAsync(*p, 0, lb.bytes, sl.st));
         }
         sl.lv.push_back(lb);
-        const mgx_slab ms{g.level, dt, g.rows, g.row0};
+        const mgx_slab ms{g.level, dt, g.rows, g.row0, 0};
         scratch = std::max(scratch, mgx_slab_scratch_doubles(&ms));
     }
     sl.c_pitch = level_pitch(d->cut, dt);
@@ -273,7 +273,7 @@ int dist_create(mgx_solver* s, const mgx_config* cfg, int rank, int world, const
 // ---- pieces of the executor ------------------------------------------------------------------------
 inline mgx_slab slab_of(const mgx_dist* d, const mgx_dist_level& g)
 {
-    return mgx_slab{g.level, d->f64 ? MGX_DTYPE_F64 : MGX_DTYPE_F32, g.rows, g.row0};
+    return mgx_slab{g.level, d->f64 ? MGX_DTYPE_F64 : MGX_DTYPE_F32, g.rows, g.row0, d->cfg.arith};
 }
 inline DistLevelBuf& buf(DistSlab& sl, int level) { return sl.lv[level - (sl.plan.c.cut + 1)]; }
 
@@ -465,11 +465,11 @@ int dist_cycle_rows(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op&
     const void* ce = nullptr;
     void* cb = nullptr;
     if (o.pre) {
-        if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, (1 << cut) + 1, 0}; ce = sl.coarse->lv[cut].u; }
+        if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, (1 << cut) + 1, 0, d->cfg.arith}; ce = sl.coarse->lv[cut].u; }
         else { cs = slab_of(d, sl.plan.L(o.level - 1)); ce = buf(sl, o.level - 1).u; }
     }
     if (o.post == 1) {
-        if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, sl.plan.c_rows, sl.plan.c_row0}; cb = sl.c_own; }
+        if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, sl.plan.c_rows, sl.plan.c_row0, d->cfg.arith}; cb = sl.c_own; }
         else { cs = slab_of(d, sl.plan.L(o.level - 1)); cb = buf(sl, o.level - 1).b; }
     }
     const int rc = mgx_slab_cycle(&fs, lb.u, lb.b, lb.tmp, row_lo, row_hi, o.mu, d->cfg.omega, d->cfg.smoother,
@@ -553,7 +553,7 @@ int dist_local_op(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op& o
             const mgx_slab fs = slab_of(d, g);
             mgx_slab cs;
             void* cb;
-            if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, sl.plan.c_rows, sl.plan.c_row0}; cb = sl.c_own; }
+            if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, sl.plan.c_rows, sl.plan.c_row0, d->cfg.arith}; cb = sl.c_own; }
             else { cs = slab_of(d, sl.plan.L(o.level - 1)); cb = buf(sl, o.level - 1).b; }
             const int rc = mgx_slab_restrict(&fs, lb.u, lb.b, &cs, cb, nullptr, o.crow_lo, o.crow_hi, d->cfg.restrict_mode, 1, (void*)sl.st);
             if (rc != MGX_OK) return s->fail(rc, "mgx_slab_restrict failed on a slab");
@@ -565,7 +565,7 @@ int dist_local_op(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op& o
             const mgx_slab fs = slab_of(d, g);
             mgx_slab cs;
             void* cb;
-            if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, sl.plan.c_rows, sl.plan.c_row0}; cb = sl.c_own; }
+            if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, sl.plan.c_rows, sl.plan.c_row0, d->cfg.arith}; cb = sl.c_own; }
             else { cs = slab_of(d, sl.plan.L(o.level - 1)); cb = buf(sl, o.level - 1).b; }
             const int rc = mgx_slab_restrict(&fs, nullptr, lb.b, &cs, cb, nullptr, o.crow_lo, o.crow_hi, d->cfg.restrict_mode, 0, (void*)sl.st);
             if (rc != MGX_OK) return s->fail(rc, "mgx_slab_restrict (right-hand side) failed on a slab");
@@ -578,7 +578,7 @@ int dist_local_op(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op& o
             const mgx_slab fs = slab_of(d, g);
             mgx_slab cs;
             const void* ce;
-            if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, (1 << cut) + 1, 0}; ce = sl.coarse->lv[cut].u; }
+            if (o.coarse_is_cut) { cs = mgx_slab{cut, dt, (1 << cut) + 1, 0, d->cfg.arith}; ce = sl.coarse->lv[cut].u; }
             else { cs = slab_of(d, sl.plan.L(o.level - 1)); ce = buf(sl, o.level - 1).u; }
             const int rc = mgx_slab_prolong(&fs, lb.u, &cs, ce, o.row_lo, o.row_hi, o.op == MGX_DOP_PROLONG ? 1 : 0, (void*)sl.st);
             if (rc != MGX_OK) return s->fail(rc, "mgx_slab_prolong failed on a slab");

@@ -357,11 +357,6 @@ template <typename T> __device__ __forceinline__ T nbr(T n, T w, T e, T s) { ret
 // Algorithmic HBM bytes per updated point: read v + read b + write v' = 3 sizeof(T).
 // Rows [row_lo,row_hi) are updated; rows row_lo-1 and row_hi are read only.
 // =============================================================================
-template <typename T>
-__device__ __forceinline__ typename VecOf<T>::type
-jacobi_vec(const typename VecOf<T>::type& up, const typename VecOf<T>::type& cur,
-           const typename VecOf<T>::type& dn, const typename VecOf<T>::type& bb, T c0, T c1);
-
 // fp32 rows are processed as two pairs so that every operation is a packed
 // v_pk_add_f32 / v_pk_mul_f32 (IEEE per component: same bits as the scalar form, and the
 // off-diagonal sum keeps the order ((N + W) + E) + S).  With cur = (x, y, z, w), l / r the
@@ -379,52 +374,72 @@ __device__ __forceinline__ NbrPairs nbr_pairs(const float4& up, const float4& cu
     return p;
 }
 
-template <>
-__device__ __forceinline__ double2 jacobi_vec<double>(const double2& up, const double2& cur, const double2& dn,
-                                                      const double2& bb, double c0, double c1)
+// One point of the sweep from cb = c1 * b (rounded once) and nb = ((N + W) + E) + S.
+//   AR = 0 (MGX_ARITH_SEPARATE, the default): every IEEE operation of PS:138-142 on its own, in the
+//           reference's order - t = c0 v + cb ; v' = t + c1 nb - bit-identical to the CPU oracle's default mode;
+//   AR = 1 (MGX_ARITH_FMA): the same expression with its two multiply-adds contracted,
+//           v' = fma(c1, nb, fma(c0, v, cb)) - two roundings fewer and 5 instead of 7 vector instructions per
+//           point (the deep passes are bound by the vector ALU); bit-identical to the oracle's
+//           FMA mode, and within north_star's 1e-10 of the default mode's residual histories (tests).
+template <int AR> __device__ __forceinline__ double jac_pt(double c0, double cur, double cb, double c1, double nb)
 {
-    const double l = from_left(cur.y), r = from_right(cur.x);
-    double2 o;
-    o.x = (c0 * cur.x + c1 * bb.x) + c1 * nbr(up.x, l, cur.y, dn.x);
-    o.y = (c0 * cur.y + c1 * bb.y) + c1 * nbr(up.y, cur.x, r, dn.y);
-    return o;
+    if constexpr (AR != 0) return __builtin_fma(c1, nb, __builtin_fma(c0, cur, cb));
+    else return (c0 * cur + cb) + c1 * nb;
 }
-template <>
-__device__ __forceinline__ float4 jacobi_vec<float>(const float4& up, const float4& cur, const float4& dn,
-                                                    const float4& bb, float c0, float c1)
+template <int AR> __device__ __forceinline__ float jac_pt(float c0, float cur, float cb, float c1, float nb)
 {
-    const NbrPairs t = nbr_pairs(up, cur, dn);
-    const f32x2 p0 = {cur.x, cur.y}, p1 = {cur.z, cur.w}, b0 = {bb.x, bb.y}, b1 = {bb.z, bb.w};
-    const f32x2 o0 = (c0 * p0 + c1 * b0) + c1 * t.t0;
-    const f32x2 o1 = (c0 * p1 + c1 * b1) + c1 * t.t1;
-    return make_float4(o0.x, o0.y, o1.x, o1.y);
+    if constexpr (AR != 0) return __builtin_fmaf(c1, nb, __builtin_fmaf(c0, cur, cb));
+    else return (c0 * cur + cb) + c1 * nb;
+}
+template <int AR> __device__ __forceinline__ f32x2 jac_pt(float c0, f32x2 cur, f32x2 cb, float c1, f32x2 nb)
+{
+    if constexpr (AR != 0) {
+        const f32x2 C0 = {c0, c0}, C1 = {c1, c1};
+        return __builtin_elementwise_fma(C1, nb, __builtin_elementwise_fma(C0, cur, cb));
+    } else {
+        return (c0 * cur + cb) + c1 * nb;
+    }
 }
 
-// the same sweep with the rhs already multiplied: cb = c1 * b (the product is rounded
-// once either way, so the result has the same bits).  The fused kernel uses a rhs row
-// at K levels; multiplying it when it is loaded saves K - 1 multiplications per point.
+// the sweep with the rhs already multiplied: cb = c1 * b.  The fused kernels use a rhs row at K
+// levels; multiplying it when it is loaded saves K - 1 multiplications per point.
+template <int AR = 0>
 __device__ __forceinline__ double2 jacobi_vec_pre(const double2& up, const double2& cur, const double2& dn,
                                                   const double2& cb, double c0, double c1)
 {
     const double l = from_left(cur.y), r = from_right(cur.x);
     double2 o;
-    o.x = (c0 * cur.x + cb.x) + c1 * nbr(up.x, l, cur.y, dn.x);
-    o.y = (c0 * cur.y + cb.y) + c1 * nbr(up.y, cur.x, r, dn.y);
+    o.x = jac_pt<AR>(c0, cur.x, cb.x, c1, nbr(up.x, l, cur.y, dn.x));
+    o.y = jac_pt<AR>(c0, cur.y, cb.y, c1, nbr(up.y, cur.x, r, dn.y));
     return o;
 }
+template <int AR = 0>
 __device__ __forceinline__ float4 jacobi_vec_pre(const float4& up, const float4& cur, const float4& dn,
                                                  const float4& cb, float c0, float c1)
 {
     const NbrPairs t = nbr_pairs(up, cur, dn);
     const f32x2 p0 = {cur.x, cur.y}, p1 = {cur.z, cur.w}, b0 = {cb.x, cb.y}, b1 = {cb.z, cb.w};
-    const f32x2 o0 = (c0 * p0 + b0) + c1 * t.t0;
-    const f32x2 o1 = (c0 * p1 + b1) + c1 * t.t1;
+    const f32x2 o0 = jac_pt<AR>(c0, p0, b0, c1, t.t0);
+    const f32x2 o1 = jac_pt<AR>(c0, p1, b1, c1, t.t1);
     return make_float4(o0.x, o0.y, o1.x, o1.y);
 }
 __device__ __forceinline__ double2 vscale(double c, const double2& v) { return make_double2(c * v.x, c * v.y); }
-__device__ __forceinline__ float4 vscale(float c, const float4& v) { return make_float4(c * v.x, c * v.y, c * v.z, c * v.w); }
+__device__ __forceinline__ float4 vscale(float c, const float4& v)
+{
+    const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+    const f32x2 x = c * a, y = c * b;
+    return make_float4(x.x, x.y, y.x, y.y);
+}
+// from the rhs itself (the product c1 * b is rounded once either way: same bits)
+template <typename T, int AR = 0>
+__device__ __forceinline__ typename VecOf<T>::type
+jacobi_vec(const typename VecOf<T>::type& up, const typename VecOf<T>::type& cur,
+           const typename VecOf<T>::type& dn, const typename VecOf<T>::type& bb, T c0, T c1)
+{
+    return jacobi_vec_pre<AR>(up, cur, dn, vscale(c1, bb), c0, c1);
+}
 
-template <typename T>
+template <typename T, int AR = 0>
 __global__ void __launch_bounds__(kBlock)
 k_jacobi(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
          int N, long pitch, int row_lo, int row_hi, int R, int strips, int chunks, T c0, T c1, int rows_alloc)
@@ -453,7 +468,7 @@ k_jacobi(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ v
         const bool more = (r + 1 < r1);
         const V dn2 = vload<V>(pv + (long)(r + 2) * pitch, has(r + 2) && more);
         const V bb2 = vload<V>(pb + (long)(r + 1) * pitch, has(r + 1) && more);
-        V o = jacobi_vec<T>(up, cur, dn, bb, c0, c1);
+        V o = jacobi_vec<T, AR>(up, cur, dn, bb, c0, c1);
         if (c.vx == 0) o.x = (T)0;          // column 0 is the Dirichlet boundary
         vstore<V>(po + (long)r * pitch, o, c.st && r >= 0 && r < rows_alloc);
         up = cur; cur = dn; dn = dn2; bb = bb2;
@@ -465,7 +480,7 @@ k_jacobi(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ v
 // and south) are served by L2 because vertically adjacent waves are dispatched
 // back to back on the same XCD.  Measured faster than the marching form on
 // MI355X at every size (tools/microbench, DESIGN.md "Kernel choices").
-template <typename T>
+template <typename T, int AR = 0>
 __global__ void __launch_bounds__(kBlock)
 k_jacobi_rows(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
               int N, long pitch, int row_lo, int row_hi, int strips, T c0, T c1, int rows_alloc)
@@ -483,7 +498,7 @@ k_jacobi_rows(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restric
     const V cur = vload<V>(pv, c.ld && in);
     const V dn = vload<V>(pv + pitch, c.ld && r >= -1 && r + 1 < rows_alloc);
     const V bb = vload<V>(rhs + c.col + (long)r * pitch, c.ld && in);
-    V o = jacobi_vec<T>(up, cur, dn, bb, c0, c1);
+    V o = jacobi_vec<T, AR>(up, cur, dn, bb, c0, c1);
     if (c.vx == 0) o.x = (T)0;
     vstore<V>(vout + c.col + (long)r * pitch, o, c.st && in);
 }
@@ -620,13 +635,13 @@ k_rbgs(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vou
 // red-black Gauss-Seidel sweep - odd levels update the red points (row + col
 // even), even levels the black ones, so s sweeps are 2 s levels; `par` is the
 // parity of (global row + first column of the vector).
-template <typename T, int SM>
+template <typename T, int SM, int AR = 0>
 __device__ __forceinline__ typename VecOf<T>::type
 level_op(int j, const typename VecOf<T>::type& up, const typename VecOf<T>::type& cur,
          const typename VecOf<T>::type& dn, const typename VecOf<T>::type& bb, T c0, T c1, int par)
 {
     if constexpr (SM == 0) {
-        return jacobi_vec<T>(up, cur, dn, bb, c0, c1);
+        return jacobi_vec<T, AR>(up, cur, dn, bb, c0, c1);
     } else {
         return ((j - 1) & 1) ? gs_colour<1>(up, cur, dn, bb, par) : gs_colour<0>(up, cur, dn, bb, par);
     }
@@ -678,7 +693,7 @@ template <typename T> constexpr int trip_steps() { return 3; }
 constexpr int kPfStages = 1;                 // prefetch slots per rotation phase (2 = six rows ahead: measured slower)
 constexpr int kPrefetch = 3 * kPfStages;     // rows a marching wave loads ahead
 
-template <typename T, int K, int SM, bool EDGE, int P, bool ZIN>
+template <typename T, int K, int SM, bool EDGE, int P, bool ZIN, int AR>
 __device__ __forceinline__ void
 fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K],
            typename VecOf<T>::type (&nin)[kPfStages], typename VecOf<T>::type (&nbn)[kPfStages], int y,
@@ -709,7 +724,7 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
         // level-j row (y - j) from level-(j-1) rows (y-j-1, y-j, y-j+1) and rhs row y-j
         const int row = y - j;
         V o;
-        if constexpr (SM == 0) o = jacobi_vec_pre(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1);
+        if constexpr (SM == 0) o = jacobi_vec_pre<AR>(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1);
         else o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], bw[j - 1], c0, c1, par_c + row);
         if constexpr (EDGE) {                                                      // Dirichlet rows and columns stay zero
             const int rw = opaque_s(row);
@@ -724,7 +739,7 @@ fused_step(typename VecOf<T>::type (&lev)[K][3], typename VecOf<T>::type (&bw)[K
     }
 }
 
-template <typename T, int K, int SM, bool EDGE, bool ZIN = false>
+template <typename T, int K, int SM, bool EDGE, bool ZIN, int AR>
 __device__ __forceinline__ void
 fused_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po, long pitch, long col, int N,
            int r0, int r1, bool ld, bool st, T c0, T c1, int bnd_lo, int bnd_hi, int rd_lo, int rd_hi, int row_parity, bool zero_in,
@@ -748,7 +763,7 @@ fused_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
 #pragma unroll
     for (int q = 0; q < kPrefetch; ++q)
         fused_loads<T, K, EDGE, ZIN>(nin[q % 3][q / 3], nbn[q % 3][q / 3], y0 + q, pv, pb, pitch, r0, r1, ld, bnd_lo, bnd_hi, rd_lo, rd_hi, zero_in, fo);
-#define MGX_FSTEP(P, Y) fused_step<T, K, SM, EDGE, P, ZIN>(lev, bw, nin[P], nbn[P], Y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in, fo)
+#define MGX_FSTEP(P, Y) fused_step<T, K, SM, EDGE, P, ZIN, AR>(lev, bw, nin[P], nbn[P], Y, pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, par_c, zero_in, fo)
     if constexpr (trip_steps<T>() == 12) {
         for (int y = y0; y < y0 + steps; y += 12) {
             MGX_FSTEP(0, y); MGX_FSTEP(1, y + 1); MGX_FSTEP(2, y + 2);
@@ -764,7 +779,7 @@ fused_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
 #undef MGX_FSTEP
 }
 
-template <typename T, int K, int SM = 0>
+template <typename T, int K, int SM = 0, int AR = 0>
 __global__ void __launch_bounds__(kBlock)
 k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
                int N, long pitch, int row_lo, int row_hi, int R, int strips, int chunks,
@@ -811,10 +826,10 @@ k_jacobi_fused(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     fo.lane_off = (unsigned)(col * (long)sizeof(T));
     fo.clane_off = 0;
     if (interior) {
-        if (zero_in) fused_body<T, K, SM, false, true>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, true, fo);
-        else fused_body<T, K, SM, false, false>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, false, fo);
+        if (zero_in) fused_body<T, K, SM, false, true, AR>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, true, fo);
+        else fused_body<T, K, SM, false, false, AR>(pv, pb, po, pitch, col, N, r0, r1, true, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, false, fo);
     } else {
-        fused_body<T, K, SM, true>(pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, zero_in != 0, fo);
+        fused_body<T, K, SM, true, false, AR>(pv, pb, po, pitch, col, N, r0, r1, ld, st, c0, c1, bnd_lo, bnd_hi, rd_lo, rd_hi, row_parity, zero_in != 0, fo);
     }
 }
 
@@ -902,7 +917,7 @@ k_residual(const T* __restrict__ vin, const T* __restrict__ rhs, void* __restric
 // 1024 threads, four independent loads per thread in flight: a V(2,1) cycle at 8192^2 hands
 // over 17 664 partials, which took 25 us with 256 threads and one load at a time.
 constexpr int kReduceThreads = 1024;
-__global__ void __launch_bounds__(kReduceThreads) k_reduce_partials(const double* __restrict__ partial, int n, double* __restrict__ out)
+static __global__ void __launch_bounds__(kReduceThreads) k_reduce_partials(const double* __restrict__ partial, int n, double* __restrict__ out)
 {
     __shared__ double wsum[kReduceThreads / kWave];
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -1230,7 +1245,7 @@ template <typename T, bool BL, bool EDGE, int POST> constexpr int cycle_cpfd() {
 
 // RP: phase of the step inside the kBRing-fold unrolled loop (BL) or inside the 3-fold one (!BL);
 // the window-rotation phase is RP % 3 either way
-template <typename T, int K, int PRE, int POST, int SM, bool EDGE, int RP, bool BL, bool ZIN>
+template <typename T, int K, int PRE, int POST, int SM, bool EDGE, int RP, bool BL, bool ZIN, int AR>
 __device__ __forceinline__ void
 cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&bw)[BL ? 1 : K + 1], lds_vec_ptr<T> ring,
            typename VecOf<T>::type (&nin)[kPfStages], typename VecOf<T>::type (&nbn)[kPfStages], PreFetch<T, VecOf<T>::W / 2>& pe,   // pe: this step's slot
@@ -1333,8 +1348,8 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
         }
         const V cb = bwin(std::integral_constant<int, j - 1>{});
         V o;
-        if constexpr (PREMUL) o = jacobi_vec_pre(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], cb, c0, c1);
-        else o = level_op<T, SM>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], cb, c0, c1,
+        if constexpr (PREMUL) o = jacobi_vec_pre<AR>(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], cb, c0, c1);
+        else o = level_op<T, SM, AR>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], cb, c0, c1,
                                  row + (int)(col & 1));
         if constexpr (EDGE) {                                                      // Dirichlet rows and columns stay zero
             const int rw = opaque_s(row);
@@ -1399,7 +1414,7 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     }
 }
 
-template <typename T, int K, int PRE, int POST, int SM, bool EDGE, bool ZIN = false>
+template <typename T, int K, int PRE, int POST, int SM, bool EDGE, bool ZIN, int AR>
 __device__ __forceinline__ double
 cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
            const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
@@ -1454,7 +1469,7 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
 #pragma unroll
         for (int q = 0; q < CPFD; ++q) coarse_loads<T, EDGE>(pe[q], y0 + q, coarse_e, cpitch, ccol, N, cld, ca.win, fo);
     }
-#define MGX_CSTEP(RP, Y) cycle_step<T, K, PRE, POST, SM, EDGE, RP, BL, ZIN>(lev, bw, ring, nin[(RP) % PFD], nbn[(RP) % PFD], pe[(RP) % CPFD], cs, Y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1, fo)
+#define MGX_CSTEP(RP, Y) cycle_step<T, K, PRE, POST, SM, EDGE, RP, BL, ZIN, AR>(lev, bw, ring, nin[(RP) % PFD], nbn[(RP) % PFD], pe[(RP) % CPFD], cs, Y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1, fo)
     if constexpr (BL) {
         // kBRing steps per trip so that every ring slot is a compile-time offset
 #define MGX_CTRIP(Y) do { MGX_CSTEP(0, Y); MGX_CSTEP(1, Y + 1); MGX_CSTEP(2, Y + 2); MGX_CSTEP(3, Y + 3); MGX_CSTEP(4, Y + 4); \
@@ -1480,7 +1495,7 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
 
 // deep passes (rhs ring in LDS): ask for two workgroups per CU = two waves per SIMD, i.e. at most 256
 // registers - without it the compiler settles for one wave per SIMD and accumulator-register spills
-template <typename T, int K, int PRE, int POST, int SM = 0>
+template <typename T, int K, int PRE, int POST, int SM = 0, int AR = 0>
 __global__ void __launch_bounds__(kBlock, (cycle_b_in_lds<T, K, POST, SM>() ? 2 : 1))
 k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
                const T* __restrict__ coarse_e,                       // PRE
@@ -1545,13 +1560,13 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         fo.clane_off = (unsigned)((col / 2) * (long)sizeof(T));
         if (interior) {
             if (PRE == 0 && zero_in)
-                acc = cycle_body<T, K, PRE, POST, SM, false, PRE == 0>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
+                acc = cycle_body<T, K, PRE, POST, SM, false, PRE == 0, AR>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
                                                                       pitch, cpitch, col, N, r0, r1, true, st, c0, c1, true, win, ring, fo);
             else
-                acc = cycle_body<T, K, PRE, POST, SM, false, false>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
+                acc = cycle_body<T, K, PRE, POST, SM, false, false, AR>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
                                                                     pitch, cpitch, col, N, r0, r1, true, st, c0, c1, false, win, ring, fo);
         } else {
-            acc = cycle_body<T, K, PRE, POST, SM, true>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
+            acc = cycle_body<T, K, PRE, POST, SM, true, false, AR>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
                                                         pitch, cpitch, col, N, r0, r1, ld, st, c0, c1, zero_in != 0, win, ring, fo);
         }
     }
@@ -1612,7 +1627,7 @@ constexpr int kTileSX = kWave;                      // 64 array columns
 
 template <int POST> constexpr int tile_extra() { return POST == 1 ? 2 : (POST == 2 ? 1 : 0); }
 
-template <typename T, int SM, int PRE, int POST>
+template <typename T, int SM, int PRE, int POST, int AR = 0>
 __global__ void __launch_bounds__(kBlock)
 k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
               const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
@@ -1692,7 +1707,7 @@ k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restric
             const T l = from_left(cur), r = from_right(cur);
             const bool rowact = (act >> i) & 1u;                                // wave-uniform
             if (SM == 0) {
-                const T o = (c0 * cur + c1 * b[i]) + c1 * nbr(prev, l, r, below);
+                const T o = jac_pt<AR>(c0, cur, c1 * b[i], c1, nbr(prev, l, r, below));
                 u[i] = (colact && rowact) ? o : cur;
             } else {
                 const T o = (T)0.25 * (b[i] + nbr(prev, l, r, below));
@@ -1770,7 +1785,7 @@ k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restric
 }
 
 // mixed precision (config 5): u64 += scale * (double) e32, rows [row_lo,row_hi)
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_axpy_f32_to_f64(double* __restrict__ u, const float* __restrict__ e, double scale, int N, long pitch, long epitch,
                   int row_lo, int row_hi, int R, int strips, int chunks, int assign)
 {
@@ -1798,7 +1813,7 @@ k_axpy_f32_to_f64(double* __restrict__ u, const float* __restrict__ e, double sc
 // neighbours' edge rows of u, which an in-place update would race with.  Same expressions,
 // same launch geometry and summation order as the two kernels it replaces: same bits.
 // Algorithmic bytes per point: 8 (u) + 4 (e) + 8 (b) + 8 (unew) + 4 (r32) = 32 (separately: 40).
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_update_residual(const double* __restrict__ u, const float* __restrict__ e, const double* __restrict__ rhs,
                   double* __restrict__ unew, float* __restrict__ r32, double scale, double inv_scale,
                   double* __restrict__ partial, int N, long pitch, long epitch, int row_lo, int row_hi,
@@ -1850,7 +1865,7 @@ k_update_residual(const double* __restrict__ u, const float* __restrict__ e, con
 }
 
 // f64 grid -> f32 grid with scaling (mixed FMG right-hand side)
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_scale_f64_to_f32(float* __restrict__ out, const double* __restrict__ in, double inv_scale, int N, long pitch_in, long pitch_out,
                    int row_lo, int row_hi, int R, int strips, int chunks)
 {

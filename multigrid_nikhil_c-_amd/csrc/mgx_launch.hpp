@@ -33,6 +33,9 @@ struct FuseCfg {
     // explicit pass plans (sweeps per pass) for the pre- / post-smoothing block of grids with
     // N >= plan_min_n: tuning knobs MGX_PLAN_PRE / MGX_PLAN_POST ("8,2"), MGX_PLAN_MIN_N
     int plan_pre[8] = {0}; int n_pre = 0; int plan_post[8] = {0}; int n_post = 0; int plan_min_n = 8192;
+    // mgx_config.arith (MGX_ARITH_*): not a tuning knob - it selects which of the two arithmetic modes of the
+    // Jacobi update every smoother kernel uses (jac_pt in mgx_kernels.hpp); set by the handle / the slab, never from the environment
+    int arith = 0;
 };
 
 // ---- typed operator launches ----------------------------------------------------
@@ -41,7 +44,7 @@ struct FuseCfg {
 // (and the kernels predicate their row loads on rows_alloc as well).
 template <typename T>
 int launch_jacobi(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
-                  double omega, int rpc, hipStream_t st, int rows_alloc)
+                  double omega, int rpc, hipStream_t st, int rows_alloc, int arith = 0)
 {
     if (row_hi <= row_lo) return MGX_OK;
     if (row_lo < 1 || row_hi > rows_alloc - 1) return MGX_ERR_INVALID;
@@ -53,13 +56,17 @@ int launch_jacobi(const T* vin, const T* b, T* vout, int N, long pitch, int row_
     if (rpc <= 0) {
         // default: one wave per row and strip (see k_jacobi_rows)
         const Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, 1);
-        hipLaunchKernelGGL((k_jacobi_rows<T>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
-                           row_lo, row_hi, g.strips, c0, c1, rows_alloc);
+        if (arith) hipLaunchKernelGGL((k_jacobi_rows<T, 1>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
+                                      row_lo, row_hi, g.strips, c0, c1, rows_alloc);
+        else hipLaunchKernelGGL((k_jacobi_rows<T, 0>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
+                                row_lo, row_hi, g.strips, c0, c1, rows_alloc);
         return MGX_OK;
     }
     const Launch g = make_launch(N, VecOf<T>::W, row_hi - row_lo, rpc);
-    hipLaunchKernelGGL((k_jacobi<T>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
-                       row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, rows_alloc);
+    if (arith) hipLaunchKernelGGL((k_jacobi<T, 1>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
+                                  row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, rows_alloc);
+    else hipLaunchKernelGGL((k_jacobi<T, 0>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
+                            row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, rows_alloc);
     return MGX_OK;
 }
 
@@ -88,7 +95,7 @@ inline int trip_rows(int R, int extra, int trip, int step)
 
 // K levels in one pass (k_jacobi_fused<T,K,SM>): K Jacobi sweeps (SM = 0) or K/2
 // red-black Gauss-Seidel sweeps (SM = 1)
-template <typename T, int K, int SM>
+template <typename T, int K, int SM, int AR>
 void launch_fused_k(const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
                     T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st, int rows_alloc, int zero_in)
 {
@@ -98,27 +105,27 @@ void launch_fused_k(const T* vin, const T* b, T* vout, int N, long pitch, int ro
     g.strips = (N / VecOf<T>::W + OUT - 1) / OUT;
     const long waves = (long)g.strips * g.chunks;
     g.blocks = (int)(((waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
-    hipLaunchKernelGGL((k_jacobi_fused<T, K, SM>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
+    hipLaunchKernelGGL((k_jacobi_fused<T, K, SM, AR>), dim3(g.blocks), dim3(kBlock), 0, st, vin, b, vout, N, pitch,
                        row_lo, row_hi, g.R, g.strips, g.chunks, c0, c1, bnd_lo, bnd_hi, row_parity, rows_alloc, zero_in);
 }
 
 // rows_alloc: number of rows the arrays hold (every load is bounded by it)
-template <typename T, int SM>
+template <typename T, int SM, int AR>
 bool launch_fused(int K, const T* vin, const T* b, T* vout, int N, long pitch, int row_lo, int row_hi,
-                  T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st, int rows_alloc, int zero_in = 0)
+                  T c0, T c1, int bnd_lo, int bnd_hi, int row_parity, int R, hipStream_t st, int rows_alloc, int zero_in)
 {
     switch (K) {
-        case 2: launch_fused_k<T, 2, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
-        case 4: launch_fused_k<T, 4, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
-        case 6: launch_fused_k<T, 6, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
-        case 8: launch_fused_k<T, 8, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
-        case 10: launch_fused_k<T, 10, SM>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
+        case 2: launch_fused_k<T, 2, SM, AR>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
+        case 4: launch_fused_k<T, 4, SM, AR>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
+        case 6: launch_fused_k<T, 6, SM, AR>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
+        case 8: launch_fused_k<T, 8, SM, AR>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
+        case 10: launch_fused_k<T, 10, SM, AR>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
         default: break;
     }
     if constexpr (SM == 0) {
         switch (K) {
-            case 3: launch_fused_k<T, 3, 0>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
-            case 5: launch_fused_k<T, 5, 0>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
+            case 3: launch_fused_k<T, 3, 0, AR>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
+            case 5: launch_fused_k<T, 5, 0, AR>(vin, b, vout, N, pitch, row_lo, row_hi, c0, c1, bnd_lo, bnd_hi, row_parity, R, st, rows_alloc, zero_in); return true;
             default: break;
         }
     }
@@ -282,14 +289,15 @@ int smooth_block(int smoother, T* a, const T* rhs, T* b2, int N, long pitch, int
             const int rd_lo = std::max(lo - K, bl), rd_hi = std::min(hi + K - 1, bh);
             if (rd_lo < 0 || rd_hi > rows_alloc - 1) return MGX_ERR_INVALID;
             if (!rbgs && sw == 1) {
-                const int rc = launch_jacobi<T>(src, rhs, dst, N, pitch, lo, hi, omega, rpc, st, rows_alloc);
+                const int rc = launch_jacobi<T>(src, rhs, dst, N, pitch, lo, hi, omega, rpc, st, rows_alloc, fc.arith);
                 if (rc) return rc;
             } else if (rbgs && !allow_fuse) {
                 launch_rbgs<T>(src, rhs, dst, N, pitch, lo, hi, row_parity, bl, bh, rpc, st);
             } else {
                 const int R = fuse_rows(fc, N, K, sizeof(T) == 8, hi - lo);
-                const bool ok = rbgs ? launch_fused<T, 1>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st, rows_alloc)
-                                     : launch_fused<T, 0>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st, rows_alloc);
+                const bool ok = rbgs ? launch_fused<T, 1, 0>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st, rows_alloc, 0)
+                                : (fc.arith ? launch_fused<T, 0, 1>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st, rows_alloc, 0)
+                                            : launch_fused<T, 0, 0>(K, src, rhs, dst, N, pitch, lo, hi, c0, c1, bl, bh, row_parity, R, st, rows_alloc, 0));
                 if (!ok) return MGX_ERR_INVALID;
             }
         }
@@ -356,7 +364,7 @@ inline int last_rows(int R, int extra, int trip) { return edge_rows(R, extra, tr
 
 // R < 0: choose the chunk height here (deep double passes: whole rounds of 2048 waves, see fuse_rows_deep;
 // -R is the height the uniform rule gave)
-template <typename T, int K, int PRE, int POST, int SM>
+template <typename T, int K, int PRE, int POST, int SM, int AR>
 int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N, long pitch, T c0, T c1, int R,
                    hipStream_t st)
 {
@@ -402,40 +410,40 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
         blocks = 8 * ((pe + pm + kWavesPerBlock - 1) / kWavesPerBlock);
     }
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
-    hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM>), dim3(blocks), dim3(kBlock), 0, st, vin, b, vout,
+    hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM, AR>), dim3(blocks), dim3(kBlock), 0, st, vin, b, vout,
                        (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
                        row_lo, row_hi, g.R, strips, g.chunks, g.Re, g.chunks_e, g.row_last0, g.Rl, c0, c1, fa.zero_in, win);
     return blocks;
 }
 
-template <typename T, int PRE, int POST, int SM>
+template <typename T, int PRE, int POST, int SM, int AR>
 int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, int N, long pitch, T c0, T c1, int R,
                  hipStream_t st)
 {
     switch (K) {
-        case 2: return launch_cycle_k<T, 2, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
-        case 4: return launch_cycle_k<T, 4, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
-        case 6: return launch_cycle_k<T, 6, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        case 2: return launch_cycle_k<T, 2, PRE, POST, SM, AR>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        case 4: return launch_cycle_k<T, 4, PRE, POST, SM, AR>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        case 6: return launch_cycle_k<T, 6, PRE, POST, SM, AR>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
         default: break;
     }
     // 8 levels: not for float passes that start from the input and end with a residual stage (with the
     // branch-free interior bodies their predicated body extracts an odd-indexed pair of a float4
     // through a stack slot: scratch)
     if constexpr (sizeof(T) == 8 || PRE == 1 || POST == 0) {
-        if (K == 8) return launch_cycle_k<T, 8, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        if (K == 8) return launch_cycle_k<T, 8, PRE, POST, SM, AR>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
     }
     // 10 levels with folded stages: double only (the float variants, whose packed arithmetic
     // needs aligned register pairs, exceed 256 VGPRs), and not the two most register-hungry
     // combinations (correction AND restriction in one pass; red-black GS with the restriction):
     // with the rhs window in LDS every instantiated variant fits 256 registers = two waves per SIMD
     if constexpr (sizeof(T) == 8 && !(PRE == 1 && POST == 1) && !(SM == 1 && POST == 1)) {
-        if (K == 10) return launch_cycle_k<T, 10, PRE, POST, SM>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+        if (K == 10) return launch_cycle_k<T, 10, PRE, POST, SM, AR>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
     }
     if constexpr (SM == 0) {
         switch (K) {
-            case 1: return launch_cycle_k<T, 1, PRE, POST, 0>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
-            case 3: return launch_cycle_k<T, 3, PRE, POST, 0>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
-            case 5: return launch_cycle_k<T, 5, PRE, POST, 0>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+            case 1: return launch_cycle_k<T, 1, PRE, POST, 0, AR>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+            case 3: return launch_cycle_k<T, 3, PRE, POST, 0, AR>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
+            case 5: return launch_cycle_k<T, 5, PRE, POST, 0, AR>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
             default: break;
         }
     }
@@ -451,7 +459,7 @@ inline bool cycle_k_supported(int K, bool rbgs, bool f64, int post = 0, bool pre
 }
 
 // ---- small levels: every sweep of a block in one launch on register tiles (k_tile_smooth) ----
-template <typename T, int SM, int PRE, int POST>
+template <typename T, int SM, int PRE, int POST, int AR>
 int launch_tile(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N, long pitch, T c0, T c1, int levels,
                 hipStream_t st)
 {
@@ -460,7 +468,7 @@ int launch_tile(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N, lo
     if (TH < 8 || TW < 8) return -1;
     const int tiles_y = (N - 1 + TH - 1) / TH, tiles_x = (N - 1 + TW - 1) / TW;
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
-    hipLaunchKernelGGL((k_tile_smooth<T, SM, PRE, POST>), dim3(tiles_y * tiles_x), dim3(kBlock), 0, st, vin, b, vout,
+    hipLaunchKernelGGL((k_tile_smooth<T, SM, PRE, POST, AR>), dim3(tiles_y * tiles_x), dim3(kBlock), 0, st, vin, b, vout,
                        (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
                        levels, c0, c1, tiles_x, fa.zero_in);
     return tiles_y * tiles_x;
@@ -468,7 +476,7 @@ int launch_tile(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N, lo
 
 // mu sweeps of a whole level, a <-> b2 ping-pong (*flips launches made); pre / post as in
 // smooth_folded_t.  Returns the number of norm partials (post == 2), < 0 on a launch error.
-template <typename T, int SM>
+template <typename T, int SM, int AR>
 int smooth_tiled(T* a, const T* rhs, T* b2, int N, long pitch, int mu, double omega, int tile_k, FoldArgs fa,
                  bool pre, int post, bool zero_in, hipStream_t st, int* flips)
 {
@@ -486,12 +494,12 @@ int smooth_tiled(T* a, const T* rhs, T* b2, int N, long pitch, int mu, double om
         const int Q = (p == np - 1) ? post : 0;
         fa.zero_in = (p == 0 && zero_in) ? 1 : 0;
         int rc;
-        if (P && Q == 2) rc = launch_tile<T, SM, 1, 2>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
-        else if (P && Q == 1) rc = launch_tile<T, SM, 1, 1>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
-        else if (P) rc = launch_tile<T, SM, 1, 0>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
-        else if (Q == 1) rc = launch_tile<T, SM, 0, 1>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
-        else if (Q == 2) rc = launch_tile<T, SM, 0, 2>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
-        else rc = launch_tile<T, SM, 0, 0>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
+        if (P && Q == 2) rc = launch_tile<T, SM, 1, 2, AR>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
+        else if (P && Q == 1) rc = launch_tile<T, SM, 1, 1, AR>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
+        else if (P) rc = launch_tile<T, SM, 1, 0, AR>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
+        else if (Q == 1) rc = launch_tile<T, SM, 0, 1, AR>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
+        else if (Q == 2) rc = launch_tile<T, SM, 0, 2, AR>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
+        else rc = launch_tile<T, SM, 0, 0, AR>(src, rhs, dst, fa, N, pitch, c0, c1, per * sw, st);
         if (rc < 0) return -1;
         if (Q == 2) blocks = rc;
         std::swap(src, dst);
@@ -553,5 +561,26 @@ void launch_residual(const T* v, const T* b, void* out, long pitch_out, double* 
     if (MODE != 0)
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kReduceThreads), 0, st, partial, g.blocks, sum_dev);
 }
+
+
+// ---- one translation unit per group of kernels --------------------------------------------------------
+// The smoother kernels are instantiated for every (type, depth, folded stages, smoother, arithmetic mode):
+// a few hundred device functions, three minutes of compile time in one translation unit.  mgx.hip therefore
+// only DECLARES the launch wrappers' instantiations; mgx_inst.hip, compiled once per group (Makefile:
+// -DMGX_INST_KIND / _T / _SMAR / _PP), defines them.  (SM, AR) pairs: Jacobi separate / Jacobi FMA / red-black GS.
+#define MGX_FOR_SMAR(X, T) X(T, 0, 0) X(T, 0, 1) X(T, 1, 0)
+#define MGX_DECL_CYCLE_PP(T, PRE, POST, SM, AR) \
+    extern template int launch_cycle<T, PRE, POST, SM, AR>(int, const T*, const T*, T*, const FoldArgs&, int, long, T, T, int, hipStream_t);
+#define MGX_DECL_CYCLE(T, SM, AR) MGX_DECL_CYCLE_PP(T, 1, 2, SM, AR) MGX_DECL_CYCLE_PP(T, 1, 0, SM, AR) MGX_DECL_CYCLE_PP(T, 0, 1, SM, AR) \
+    MGX_DECL_CYCLE_PP(T, 0, 2, SM, AR) MGX_DECL_CYCLE_PP(T, 1, 1, SM, AR)
+#define MGX_DECL_FUSED(T, SM, AR) \
+    extern template bool launch_fused<T, SM, AR>(int, const T*, const T*, T*, int, long, int, int, T, T, int, int, int, int, hipStream_t, int, int);
+#define MGX_DECL_TILE(T, SM, AR) \
+    extern template int smooth_tiled<T, SM, AR>(T*, const T*, T*, int, long, int, double, int, FoldArgs, bool, int, bool, hipStream_t, int*);
+#if !defined(MGX_INST_KIND) && !defined(MGX_SINGLE_TU)
+MGX_FOR_SMAR(MGX_DECL_CYCLE, double) MGX_FOR_SMAR(MGX_DECL_CYCLE, float)
+MGX_FOR_SMAR(MGX_DECL_FUSED, double) MGX_FOR_SMAR(MGX_DECL_FUSED, float)
+MGX_FOR_SMAR(MGX_DECL_TILE, double) MGX_FOR_SMAR(MGX_DECL_TILE, float)
+#endif
 
 } // namespace mgx

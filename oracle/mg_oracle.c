@@ -61,6 +61,7 @@ void orc_config_default(orc_config* c)
     c->schedule = ORC_SCHEDULE_FMG; /* PS:727 calls fullmultigrid */
     c->restrict_mode = ORC_RESTRICT_CONSISTENT;
     c->bottom = ORC_BOTTOM_EXACT;
+    c->arith = ORC_ARITH_SEPARATE;
 }
 
 /* ---- exact bottom solver: banded Cholesky (stands in for Eigen SparseLU,
@@ -181,13 +182,21 @@ static void orc_dst_solve(orc_solver* s, double* x)
 /* ---- type-generic operators and schedules ------------------------------ */
 #define REAL double
 #define SUF(x) x##_f64
+#define ORC_FMA(a, b, c) fma((a), (b), (c))
+#define ORC_FMA_HW(a, b, c) __builtin_fma((a), (b), (c))
 #include "mg_oracle_impl.inc"
+#undef ORC_FMA
+#undef ORC_FMA_HW
 #undef REAL
 #undef SUF
 
 #define REAL float
 #define SUF(x) x##_f32
+#define ORC_FMA(a, b, c) fmaf((a), (b), (c))
+#define ORC_FMA_HW(a, b, c) __builtin_fmaf((a), (b), (c))
 #include "mg_oracle_impl.inc"
+#undef ORC_FMA
+#undef ORC_FMA_HW
 #undef REAL
 #undef SUF
 

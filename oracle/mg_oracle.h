@@ -48,6 +48,10 @@ enum { ORC_SCHEDULE_V = 0, ORC_SCHEDULE_FMG = 1 };
 enum { ORC_RESTRICT_CONSISTENT = 0, ORC_RESTRICT_FW16 = 1 };
 enum { ORC_BOTTOM_EXACT = 0, ORC_BOTTOM_SMOOTH = 1,
        ORC_BOTTOM_DST = 2 /* exact too: sine transform, in the device's operation order (mg_oracle.c) */ };
+/* how the Jacobi update of PS:138-142 is rounded: the reference's five library calls as five roundings
+ * (SEPARATE, the default), or the same expression with its two multiply-adds contracted (FMA) - what a
+ * fused kernel may do; mirrors MGX_ARITH_* of include/mgx.h so that BOTH device modes have a bit-exact check */
+enum { ORC_ARITH_SEPARATE = 0, ORC_ARITH_FMA = 1 };
 
 /* Mirrors the reference's compile-time globals (PS:17-22, PS:127) as run-time
  * fields; same field order as mgx_config in include/mgx.h. */
@@ -63,6 +67,7 @@ typedef struct {
     int schedule;        /* ORC_SCHEDULE_* */
     int restrict_mode;   /* ORC_RESTRICT_* (D4) */
     int bottom;          /* ORC_BOTTOM_* (D8) */
+    int arith;           /* ORC_ARITH_* */
 } orc_config;
 
 void orc_config_default(orc_config* c);
@@ -71,6 +76,9 @@ void orc_config_default(orc_config* c);
 /* PS:125-147 weighted Jacobi, mu sweeps, in place (uses an internal copy). */
 void orc_jacobi_f64(double* v, const double* f, int n, int mu, double omega);
 void orc_jacobi_f32(float* v, const float* f, int n, int mu, double omega);
+/* the same sweeps in arithmetic mode `arith`: v' = fma(c1, nb, fma(c0, v, c1 f)) when ORC_ARITH_FMA */
+void orc_jacobi_arith_f64(double* v, const double* f, int n, int mu, double omega, int arith);
+void orc_jacobi_arith_f32(float* v, const float* f, int n, int mu, double omega, int arith);
 /* red-black Gauss-Seidel (absent from the reference). */
 void orc_rbgs_f64(double* v, const double* f, int n, int mu);
 void orc_rbgs_f32(float* v, const float* f, int n, int mu);

@@ -20,6 +20,7 @@ DTYPE_F32, DTYPE_F64, DTYPE_MIXED = 0, 1, 2
 SCHEDULE_V, SCHEDULE_FMG = 0, 1
 RESTRICT_CONSISTENT, RESTRICT_FW16 = 0, 1
 BOTTOM_EXACT, BOTTOM_SMOOTH, BOTTOM_DST = 0, 1, 2
+ARITH_SEPARATE, ARITH_FMA = 0, 1
 
 
 class Config(C.Structure):
@@ -28,7 +29,7 @@ class Config(C.Structure):
         ("mu0", C.c_int), ("mu1", C.c_int), ("mu2", C.c_int),
         ("omega", C.c_double),
         ("smoother", C.c_int), ("dtype", C.c_int), ("schedule", C.c_int),
-        ("restrict_mode", C.c_int), ("bottom", C.c_int),
+        ("restrict_mode", C.c_int), ("bottom", C.c_int), ("arith", C.c_int),
     ]
 
 
@@ -53,6 +54,7 @@ def lib() -> C.CDLL:
         dp, fp, vp = C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_void_p
         for suf, p in (("f64", dp), ("f32", fp)):
             getattr(L, f"orc_jacobi_{suf}").argtypes = [p, p, C.c_int, C.c_int, C.c_double]
+            getattr(L, f"orc_jacobi_arith_{suf}").argtypes = [p, p, C.c_int, C.c_int, C.c_double, C.c_int]
             getattr(L, f"orc_rbgs_{suf}").argtypes = [p, p, C.c_int, C.c_int]
             getattr(L, f"orc_residual_{suf}").argtypes = [p, p, p, C.c_int]
             getattr(L, f"orc_restrict_{suf}").argtypes = [p, p, C.c_int, C.c_int]
@@ -103,10 +105,10 @@ def default_config(**kw) -> Config:
 
 
 # -- operators on interior n x n arrays (2-D numpy, C order) -------------------
-def jacobi(v, f, mu, omega=2.0 / 3.0):
+def jacobi(v, f, mu, omega=2.0 / 3.0, arith=ARITH_SEPARATE):
     v = np.array(v, copy=True, order="C")
     f = np.ascontiguousarray(f, dtype=v.dtype)
-    getattr(lib(), f"orc_jacobi_{_suf(v)}")(_ptr(v), _ptr(f), v.shape[0], mu, omega)
+    getattr(lib(), f"orc_jacobi_arith_{_suf(v)}")(_ptr(v), _ptr(f), v.shape[0], mu, omega, arith)
     return v
 
 

@@ -89,23 +89,24 @@ def test_no_cpu_fallback(pkg):
     assert pkg.lib().mgx_slab_scratch_doubles(C.byref(s)) == -1
 
 
-def test_no_kernel_uses_scratch(tmp_path):
+def test_no_kernel_uses_scratch():
     """Register-resident row windows are the whole point of the fused kernels: a
-    spill (scratch) silently costs 30-60 %.  Cross-compile for gfx950 and check
-    every kernel's ScratchSize (this caught a run-time-indexed state array)."""
+    spill (scratch) silently costs 30-60 %.  Every compile of the library leaves its kernels'
+    resource usage in csrc/build/*.remarks (-Rpass-analysis=kernel-resource-usage): bring the build
+    up to date and check every kernel's ScratchSize (this caught a run-time-indexed state array)."""
+    import glob
     import shutil
     import subprocess
 
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    src = os.path.join(ROOT, "multigrid_nikhil_c-_amd", "csrc", "mgx.hip")
-    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-                          "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "chk.so"), src],
-                         capture_output=True, text=True, timeout=900)
+    csrc = os.path.join(ROOT, "multigrid_nikhil_c-_amd", "csrc")
+    out = subprocess.run(["make", "-C", csrc], capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
-    sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
-    assert len(sizes) > 50, "resource-usage remarks missing"
+    txt = "".join(open(f).read() for f in glob.glob(os.path.join(csrc, "build", "*.remarks")))
+    sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", txt)]
+    assert len(sizes) > 300, "resource-usage remarks missing"
     assert max(sizes) == 0, f"{sum(1 for x in sizes if x)} kernels use scratch (max {max(sizes)} B/lane)"
 
 

@@ -187,3 +187,39 @@ def test_sine_transform_bottom_mode_agrees_with_cholesky(po):
         x32 = s32.bottom_solve(b.astype(np.float32))
         s64 = po.Solver(finest_level=level, coarsest_level=level, bottom=po.BOTTOM_DST)
         assert np.array_equal(x32, s64.bottom_solve(b.astype(np.float32).astype(np.float64)).astype(np.float32))
+
+
+def test_fma_mode_is_the_contracted_jacobi_update(po):
+    """ORC_ARITH_FMA == v' = fma(c1, nb, fma(c0, v, c1 f)) with exactly rounded fused operations
+    (checked with rational arithmetic), and differs from the default mode by rounding only"""
+    from fractions import Fraction as F
+
+    rng = np.random.default_rng(5)
+    n = 9
+    v = rng.standard_normal((n, n))
+    f = rng.standard_normal((n, n))
+    om = 2.0 / 3.0
+    c0, c1 = 1.0 - om, om / 4.0
+    out = po.jacobi(v, f, 1, om, arith=po.ARITH_FMA)
+
+    def fma(a, b, c):
+        return float(F(a) * F(b) + F(c))       # one rounding (float(Fraction) rounds to nearest even)
+
+    vp = np.pad(v, 1)
+    for i in range(n):
+        for j in range(n):
+            nb = ((vp[i, j + 1] + vp[i + 1, j]) + vp[i + 1, j + 2]) + vp[i + 2, j + 1]      # N, W, E, S
+            assert out[i, j] == fma(c1, nb, fma(c0, v[i, j], c1 * f[i, j])), (i, j)
+    sep = po.jacobi(v, f, 1, om)
+    assert not np.array_equal(out, sep) and np.max(np.abs(out - sep)) <= 4 * np.finfo(float).eps * np.max(np.abs(sep))
+    # exact data (small integers, dyadic weights): both modes give the same values, in both precisions
+    for dt in (np.float64, np.float32):
+        vi = rng.integers(-8, 9, (n, n)).astype(dt)
+        fi = rng.integers(-8, 9, (n, n)).astype(dt)
+        assert np.array_equal(po.jacobi(vi, fi, 3, 0.5, arith=po.ARITH_FMA), po.jacobi(vi, fi, 3, 0.5))
+    # a solver in FMA mode follows the default one to rounding
+    cfg = dict(finest_level=6, coarsest_level=4, mu1=2, mu2=2, schedule=0)
+    b = po.rhs_sine(6)
+    _, h0 = po.Solver(**cfg).solve(b, None, tol=1e-9, max_cycles=20)
+    _, h1 = po.Solver(arith=po.ARITH_FMA, **cfg).solve(b, None, tol=1e-9, max_cycles=20)
+    assert len(h0) == len(h1) and np.all(np.abs(h0 - h1) <= 1e-10 * h0 + 1e-13 * h0[0])
