@@ -16,9 +16,10 @@ inside the time but only fine-grid updates are counted.
                     [--smoother jacobi|rbgs] [--mu1 A --mu2 B] [--no-cpu-baseline]
 
 N = 1 : one process, libmgx (C-ABI) through ctypes, HIP events for the roofline.
-N > 1 : one process per GPU (torch.distributed over RCCL), the finest levels
-        slab-decomposed by rows with halo exchange between smoothing blocks
-        (multigrid_nikhil_c-_amd/dist.py).  Default grid 16384^2 (BASELINE config 4,
+N > 1 : one process per GPU (ranks from torch.distributed.run or from this script's own launcher;
+        RCCL inside libmgx, a small TCP store as control plane - no torch in a rank process), the
+        finest levels slab-decomposed by rows with halo exchange between smoothing blocks
+        (csrc/mgx_dist.hpp, multigrid_nikhil_c-_amd/dist_bench.py).  Default grid 16384^2 (BASELINE config 4,
         the north star's strong-scaling grid), the same at every N > 1; rank 0 also
         times the single-GPU solver on that same grid inside the job and reports it
         (`single_gpu_same_workload`) so the strong-scaling factor is like for like.
@@ -333,80 +334,135 @@ def free_port():
 
 
 def visible_devices():
-    """HIP devices this process could use, WITHOUT initialising the GPU (the launcher must stay
-    a process that never touched it: its children are the ranks)."""
+    """HIP devices this process could use, counted WITHOUT any runtime (the launcher must stay a process that
+    never touched the GPU: its children are the ranks): the visibility variables if set, else the KFD
+    topology nodes that have compute units."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
     try:
-        import torch
-
-        return int(torch.cuda.device_count())
-    except Exception:
+        for node in os.listdir(base):
+            try:
+                props = dict(ln.split()[:2] for ln in open(os.path.join(base, node, "properties")) if len(ln.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                pass
+    except OSError:
         return 0
+    return n
+
+
+def null_line(args, n, error):
+    return {"metric": "fine_grid_stencil_updates_per_sec", "value": None, "unit": "updates/s", "n_gpus": n,
+            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"2D Poisson {1 << (args.level or 14)}^2, row slabs over {n} GPUs"}, "error": error}
 
 
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` started as ONE plain process (no torchrun): become the launcher.
     Start exactly N child ranks of this same script, one per GPU, with RANK / LOCAL_RANK /
-    WORLD_SIZE / MASTER_* set; relay rank 0's single JSON line; fail if any rank fails.  Nothing
-    here touches the GPU and nothing is exec'ed over a process that did."""
+    WORLD_SIZE / MASTER_* set; relay rank 0's single JSON line.  Every child is supervised: on the
+    first non-zero exit (a GPU fault, an RCCL error, a timed-out rendezvous) the others are terminated,
+    then killed, a `value: null` line is printed and the launcher exits non-zero; the whole job has a
+    deadline (MGX_BENCH_DEADLINE seconds, default 1500).  Nothing here touches the GPU and nothing is
+    exec'ed over a process that did."""
     import subprocess
+    import tempfile
 
     n = args.gpus
     rehearsal = bool(os.environ.get("MGX_DIST_SINGLE_DEVICE")) or bool(os.environ.get("MGX_BENCH_DRYRUN"))
     ndev = visible_devices()
     if ndev < n and not rehearsal:
-        emit({"metric": "fine_grid_stencil_updates_per_sec", "value": None, "unit": "updates/s", "n_gpus": n,
-              "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong",
-              "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-              "config": {"workload": f"2D Poisson {1 << (args.level or 14)}^2, row slabs over {n} GPUs"},
-              "error": f"--gpus {n} needs {n} HIP devices, {ndev} visible (rehearsal on fewer devices: "
-                       f"MGX_DIST_SINGLE_DEVICE=1 MGX_DIST_BACKEND=gloo)"})
+        emit(null_line(args, n, f"--gpus {n} needs {n} HIP devices, {ndev} visible (rehearsal on fewer devices: "
+                                f"MGX_DIST_SINGLE_DEVICE=1 MGX_DIST_BACKEND=staged)"))
         sys.exit(2)
-    port = free_port()
+    port, rdzv_port = free_port(), free_port()
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MGX_BENCH_LAUNCHED="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MGX_RDZV_PORT=str(rdzv_port), MGX_BENCH_LAUNCHED="1")
         # rank 0's stdout is the result line; every rank's stderr goes to ours
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=2))
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=2))
     if os.environ.get("MGX_BENCH_LAUNCH_LOG"):       # tests: which ranks were started
         with open(os.environ["MGX_BENCH_LAUNCH_LOG"], "w") as fh:
             json.dump({"ranks": n, "pids": [p.pid for p in procs], "port": port}, fh)
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    deadline = time.monotonic() + float(os.environ.get("MGX_BENCH_DEADLINE", "1500"))
+    failure = None
+    while failure is None:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failure = "rank(s) " + ", ".join(f"{r} exited with code {c}" for r, c in bad)
+        elif all(c == 0 for c in codes):
+            break
+        elif time.monotonic() > deadline:
+            failure = "deadline exceeded"
+        else:
+            time.sleep(0.05)
+    if failure is not None:
+        for p in procs:                              # exactly the processes started here, by pid
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    out0.seek(0)
     line = None
-    for ln in (out0 or b"").decode(errors="replace").splitlines():
+    for ln in out0.read().decode(errors="replace").splitlines():
         if ln.lstrip().startswith("{"):
             line = ln
-    if line is not None:
+    codes = [p.returncode for p in procs]
+    if failure is None and line is not None:
         os.write(_REAL_STDOUT, (line + "\n").encode())
-    if any(codes) or line is None:
-        sys.stderr.write(f"bench.py launcher: rank exit codes {codes}, result line {'present' if line else 'MISSING'}\n")
-        sys.exit(1)
+        return
+    sys.stderr.write(f"bench.py launcher: {failure or 'no result line'}; rank exit codes {codes}\n")
+    # a rank's own error line (value null) is relayed; anything else is replaced by one
+    relay = None
+    if line is not None:
+        try:
+            relay = line if json.loads(line).get("value") is None else None
+        except ValueError:
+            relay = None
+    if relay is not None:
+        os.write(_REAL_STDOUT, (relay + "\n").encode())
+    else:
+        emit(null_line(args, n, f"launcher: {failure or 'rank 0 printed no result line'}; rank exit codes {codes}"))
+    sys.exit(1)
 
 
 def dry_run(args, world):
-    """MGX_BENCH_DRYRUN=1 (tests/test_bench_launcher.py, CPU): every rank joins a gloo group and is
-    counted by an all_reduce; rank 0 prints the line shape with the rank count the collective saw.
+    """MGX_BENCH_DRYRUN=1 (tests/test_bench_launcher.py, CPU): every rank joins the job's store and is
+    counted by a collective; rank 0 prints the line shape with the rank count the collective saw.
     No solver, no GPU: this exercises the launcher and the rendezvous only."""
-    import torch
-    import torch.distributed as dist
-
     seen = 1
-    if os.environ.get("MGX_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):
-        sys.exit(7)                     # test hook: a rank that dies
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("MGX_BENCH_FAIL_RANK") == str(rank):
+        sys.exit(7)                     # test hook: a rank that dies before the rendezvous
     if world > 1:
-        import datetime
+        import __graft_entry__ as ge
 
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=20))
-        t = torch.ones(1, dtype=torch.int64)
-        dist.all_reduce(t)
-        seen = int(t.item())
-        rank = dist.get_rank()
-        dist.barrier()
-        dist.destroy_process_group()
-    else:
-        rank = 0
+        ge.load_package()
+        from multigrid_nikhil_c_amd.rendezvous import Store
+
+        store = Store(rank, world, timeout=float(os.environ.get("MGX_RDZV_TIMEOUT", "20")))
+        seen = store.allreduce_sum_int(1)
+        if os.environ.get("MGX_BENCH_FAIL_LATE_RANK") == str(rank):
+            os._exit(9)                 # test hook: a rank that dies in the middle of the job
+        if os.environ.get("MGX_BENCH_HANG_RANK") == str(rank):
+            time.sleep(3600)            # test hook: a rank that never comes back
+        store.barrier()
+        store.close()
     if seen != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but the collective saw {seen} ranks\n")
         sys.exit(3)
@@ -448,11 +504,7 @@ def main():
 
         traceback.print_exc()
         if int(os.environ.get("RANK", "0")) == 0:
-            emit({"metric": "fine_grid_stencil_updates_per_sec", "value": None, "unit": "updates/s",
-                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
-                  "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                  "config": {"workload": f"2D Poisson {1 << args.level}^2, row slabs over {world} GPUs"},
-                  "error": f"{type(e).__name__}: {e}"})
+            emit(null_line(args, world, f"{type(e).__name__}: {e}"))
         raise
 
 

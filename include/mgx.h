@@ -45,7 +45,17 @@ typedef enum {
 enum { MGX_SMOOTHER_JACOBI = 0, MGX_SMOOTHER_RBGS = 1 };
 enum { MGX_DTYPE_F32 = 0, MGX_DTYPE_F64 = 1, MGX_DTYPE_MIXED = 2 };
 enum { MGX_SCHEDULE_V = 0, MGX_SCHEDULE_FMG = 1 };
-enum { MGX_RESTRICT_CONSISTENT = 0, MGX_RESTRICT_FW16 = 1 };
+enum { MGX_RESTRICT_CONSISTENT = 0, MGX_RESTRICT_FW16 = 1,
+       MGX_RESTRICT_INJECT = 2,    /* MF:122-130 restriction2D as written: the fine value at the coincident node */
+       MGX_RESTRICT_INJECT4 = 3 }; /* 4 x injection: the h^2-consistent weight for operators that carry no h^-2 (cf. D4) */
+/* Operator of the hierarchy.  POISSON: the constant five-point stencil of PS (matrix-free, fused kernels).
+ * STENCIL5: the data model of the reference's second draft (MF:16-41 ProblemVar) on the structured grid - one
+ * general five-point operator PER LEVEL (A_sp_dict[level]) given by the caller as five coefficient grids
+ * (mgx_set_stencil) or re-discretised from a nodal coefficient a(x, y) of -div(a grad u) (mgx_set_coefficient),
+ * smoothed in MF's form  v <- R_omega v + omega D^-1 b  (MF:86-93), residual b - A v (MF:150-153), direct solve of
+ * the coarsest operator (MF:63-72: dense inverse; coarsest_level <= 5).  dtype F64 / F32, Jacobi, one GPU.
+ * Algorithmic bytes per point and sweep: 8 sizeof(T) (v, b, D_inv, four R arrays in; v' out). */
+enum { MGX_OPERATOR_POISSON = 0, MGX_OPERATOR_STENCIL5 = 1 };
 enum { MGX_BOTTOM_EXACT = 0, MGX_BOTTOM_SMOOTH = 1 };
 /* Arithmetic of the weighted-Jacobi update  v' = (1-w) v + (w/4) b + (w/4)(N+W+E+S)  (PS:138-142):
  *   SEPARATE: the reference's five library calls as five roundings per point, in its order
@@ -91,6 +101,7 @@ typedef struct {
     int cut_level;        /* 0: chosen from the grid and n_gpus */
     int devices[MGX_MAX_GPUS];   /* -1 entries: slab g on device g modulo the device count */
     int arith;            /* MGX_ARITH_*     (PS:138-142: how the Jacobi update is rounded) */
+    int op;               /* MGX_OPERATOR_*  (MF:16-41: per-level general operators) */
 } mgx_config;
 
 typedef struct mgx_solver* mgx_handle;
@@ -149,6 +160,24 @@ MGX_API int mgx_zero_level(mgx_handle h, int level, int which);
 MGX_API int mgx_fill_rhs(mgx_handle h, int kind, double f);
 /* u ~ U(-1,1) from a counter-based generator keyed on (seed, index). */
 MGX_API int mgx_fill_guess_random(mgx_handle h, uint64_t seed);
+
+/* ---- general per-level operators: ProblemVar (MF:16-41), handles with op = MGX_OPERATOR_STENCIL5 -----------
+ * A_sp_dict[level] (MF:19; csr_matrix_elements MF:33-41) as five coefficient grids in the host layout of every
+ * vector (interior n x n, row-major, element type = the handle's working type):
+ *     (A u)_ij = c u_ij + n u_(i-1)j + s u_(i+1)j + w u_i(j-1) + e u_i(j+1)
+ * (coefficients that point at the eliminated Dirichlet ring are ignored, PS:188-198).  The call also builds
+ * A_jacobi_sp_dict[level] = {D_inv, R_omega = I - omega D^-1 A} (MF:20, 28-32) and, on the coarsest level, the
+ * direct solver of coarsest_level_matrix (MF:18, 63-72).  Every level must be given before a schedule runs
+ * (MGX_ERR_STATE otherwise): as in MF, coarse operators are the caller's (the Python front-end of MF:1-3). */
+MGX_API int mgx_set_stencil(mgx_handle h, int level, const void* c, const void* n, const void* s, const void* w,
+                            const void* e, size_t count);
+/* All levels at once from the nodal coefficient a >= a_min > 0 of  -div(a grad u)  on the finest grid's
+ * (N + 1)^2 nodes (double, row-major, boundary nodes included): each level samples a at its own nodes and takes
+ * face values as the mean of the two nodes (w = -(a_ij + a_i,j-1)/2 ..., c = -(n + s + w + e)): the re-discretised
+ * hierarchy of MF:184.  a = 1 gives the Poisson stencil. */
+MGX_API int mgx_set_coefficient(mgx_handle h, const double* a_nodes, size_t count);
+/* read back: which = 0..4 the operator (c, n, s, w, e), 5..9 its Jacobi splitting (D_inv, R_n, R_s, R_w, R_e) */
+MGX_API int mgx_get_stencil(mgx_handle h, int level, int which, void* dst, size_t count);
 
 /* ---- grid operators (one call = the reference function named) ------------
  * On a dtype MIXED handle the finest level holds double data for the accessors above and a
@@ -387,6 +416,12 @@ MGX_API long mgx_dist_exchanges(mgx_handle h);
  * need no halo (the pass then finishes with its two edge bands).  Opt-in, MGX_DIST_OVERLAP=1: a band is a
  * 10-level launch of ~50 us however thin it is, more than a halo message of this size takes */
 MGX_API long mgx_dist_overlapped(mgx_handle h);
+/* The ROCm runtime libraries this process has mapped (libamdhip64, libhsa-runtime64, librccl, libmgx ...), one
+ * path per line, from /proc/self/maps.  libmgx is built against /opt/rocm (RUNPATH); a host application that
+ * loaded another copy with the same SONAME first - the torch wheel bundles its own - would run this library on
+ * that stack.  bench.py reports the list (`runtime_libs`); MGX_LOG_RUNTIME_LIBS=1 prints it at every
+ * mgx_create / mgx_create_rank.  Returns the bytes written (without the terminator), < 0 on error. */
+MGX_API int mgx_runtime_libs(char* buf, size_t cap);
 /* plain copies for callers that implement a transport without a HIP binding of their own */
 MGX_API int mgx_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 MGX_API int mgx_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);

@@ -9,7 +9,7 @@ the reference's name, so import it through __graft_entry__.load_package()
 """
 from .binding import (  # noqa: F401
     ARITH_FMA, ARITH_SEPARATE, BOTTOM_EXACT, BOTTOM_SMOOTH, DTYPE_F32, DTYPE_F64, DTYPE_MIXED, EXPORTS, LIB_PATH,
-    RESTRICT_CONSISTENT, RESTRICT_FW16, SCHEDULE_FMG, SCHEDULE_V, SMOOTHER_JACOBI,
+    OPERATOR_POISSON, OPERATOR_STENCIL5, RESTRICT_CONSISTENT, RESTRICT_FW16, RESTRICT_INJECT, RESTRICT_INJECT4, SCHEDULE_FMG, SCHEDULE_V, SMOOTHER_JACOBI,
     SMOOTHER_RBGS, VEC_B, VEC_R, VEC_U, Config, DistLevel, DistOp, MgxError, Multigrid, Plan, Slab, Transport, Xfer,
-    default_config, lib, rccl_unique_id,
+    default_config, lib, rccl_unique_id, runtime_libs,
 )

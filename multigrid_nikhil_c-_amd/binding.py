@@ -23,7 +23,8 @@ LIB_PATH = os.environ.get("MGX_LIBMGX_PATH") or os.path.join(_HERE, "libmgx.so")
 SMOOTHER_JACOBI, SMOOTHER_RBGS = 0, 1
 DTYPE_F32, DTYPE_F64, DTYPE_MIXED = 0, 1, 2
 SCHEDULE_V, SCHEDULE_FMG = 0, 1
-RESTRICT_CONSISTENT, RESTRICT_FW16 = 0, 1
+RESTRICT_CONSISTENT, RESTRICT_FW16, RESTRICT_INJECT, RESTRICT_INJECT4 = 0, 1, 2, 3
+OPERATOR_POISSON, OPERATOR_STENCIL5 = 0, 1
 BOTTOM_EXACT, BOTTOM_SMOOTH = 0, 1
 ARITH_SEPARATE, ARITH_FMA = 0, 1
 VEC_U, VEC_B, VEC_R = 0, 1, 2
@@ -41,7 +42,8 @@ EXPORTS = [
     "mgx_slab_residual_sumsq", "mgx_slab_scratch_doubles",
     "mgx_plan_create", "mgx_plan_destroy", "mgx_plan_last_error", "mgx_plan_cut_level", "mgx_plan_level",
     "mgx_plan_cut_share", "mgx_plan_guess_set", "mgx_plan_vcycle", "mgx_plan_norm", "mgx_plan_fmg", "mgx_rccl_unique_id",
-    "mgx_create_rank", "mgx_dist_exchanges", "mgx_dist_overlapped", "mgx_memcpy_d2h", "mgx_memcpy_h2d",
+    "mgx_create_rank", "mgx_dist_exchanges", "mgx_dist_overlapped", "mgx_memcpy_d2h", "mgx_memcpy_h2d", "mgx_runtime_libs",
+    "mgx_set_stencil", "mgx_set_coefficient", "mgx_get_stencil",
 ]
 MAX_GPUS = 16
 (DOP_EXCHANGE, DOP_ZERO_U, DOP_CYCLE, DOP_SMOOTH, DOP_RESTRICT, DOP_PROLONG, DOP_GATHER_CUT, DOP_COARSE, DOP_SUMSQ,
@@ -57,7 +59,7 @@ class Config(C.Structure):
         ("restrict_mode", C.c_int), ("bottom", C.c_int),
         ("device", C.c_int), ("profile", C.c_int),
         ("n_gpus", C.c_int), ("cut_level", C.c_int), ("devices", C.c_int * MAX_GPUS),
-        ("arith", C.c_int),
+        ("arith", C.c_int), ("op", C.c_int),
     ]
 
 
@@ -187,8 +189,20 @@ def lib() -> C.CDLL:
     L.mgx_dist_overlapped.restype = C.c_long
     L.mgx_memcpy_d2h.argtypes = [vp, vp, C.c_size_t, vp]
     L.mgx_memcpy_h2d.argtypes = [vp, vp, C.c_size_t, vp]
+    L.mgx_runtime_libs.argtypes = [C.c_char_p, C.c_size_t]
+    L.mgx_set_stencil.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_size_t]
+    L.mgx_set_coefficient.argtypes = [vp, vp, C.c_size_t]
+    L.mgx_get_stencil.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
     _lib = L
     return L
+
+
+def runtime_libs() -> list[str]:
+    """paths of the ROCm runtime libraries (and libmgx) mapped into this process (mgx_runtime_libs)"""
+    buf = C.create_string_buffer(16384)
+    if lib().mgx_runtime_libs(buf, len(buf)) < 0:
+        return []
+    return [p for p in buf.value.decode().splitlines() if p]
 
 
 def lib_loaded() -> bool:
@@ -374,6 +388,24 @@ class Multigrid:
         rows it owns and leaves the others untouched)"""
         assert a.flags["C_CONTIGUOUS"] and a.dtype == self.level_dtype(self.cfg.finest_level)
         self._chk(lib().mgx_get_solution(self._h, a.ctypes.data, a.size), "mgx_get_solution")
+        return a
+
+    # -- general per-level operators (MF:16-41) ---------------------------------------
+    def set_stencil(self, level, c, n, s, w, e):
+        """ProblemVar::A_sp_dict[level]: five interior n x n coefficient arrays"""
+        dt = self.level_dtype(level)
+        a = [np.ascontiguousarray(x, dtype=dt) for x in (c, n, s, w, e)]
+        self._chk(lib().mgx_set_stencil(self._h, level, *[x.ctypes.data for x in a], a[0].size), "mgx_set_stencil")
+
+    def set_coefficient(self, a_nodes):
+        """every level's operator from the nodal coefficient of -div(a grad u) on the finest grid ((N + 1)^2 doubles)"""
+        a = np.ascontiguousarray(a_nodes, dtype=np.float64)
+        self._chk(lib().mgx_set_coefficient(self._h, a.ctypes.data, a.size), "mgx_set_coefficient")
+
+    def get_stencil(self, level, which):
+        n = self.n(level)
+        a = np.empty((n, n), dtype=self.level_dtype(level))
+        self._chk(lib().mgx_get_stencil(self._h, level, which, a.ctypes.data, a.size), "mgx_get_stencil")
         return a
 
     def fill_rhs(self, kind=0, f=4.0):

@@ -14,9 +14,11 @@
 #include "mgx_bottom.hpp"
 #include "mgx_kernels.hpp"
 #include "mgx_launch.hpp"
+#include "mgx_var.hpp"
 #include "mgx_dist_plan.hpp"
 
 #include <chrono>
+#include <unistd.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,12 +32,26 @@ using namespace mgx;
 
 thread_local std::string g_create_error;
 
+// MGX_LOG_RUNTIME_LIBS=1: print the mapped ROCm runtime libraries when a handle is created (mgx_runtime_libs)
+void log_runtime_libs(const char* where)
+{
+    if (env_int("MGX_LOG_RUNTIME_LIBS", 0) == 0) return;
+    char buf[8192];
+    if (mgx_runtime_libs(buf, sizeof buf) >= 0)
+        std::fprintf(stderr, "[mgx] runtime libraries mapped at %s (pid %d):\n%s", where, (int)getpid(), buf);
+}
+
 struct Level {
     int L = 0, N = 0, rows = 0;
     long pitch = 0;
     size_t bytes = 0;
     bool f64 = true;
     void *u = nullptr, *b = nullptr, *tmp = nullptr, *r = nullptr;
+    // MGX_OPERATOR_STENCIL5 (mgx_var.hpp): A = (c, n, s, w, e)  [ProblemVar::A_sp_dict, MF:19] and its Jacobi
+    // splitting (D_inv, R_n, R_s, R_w, R_e)  [A_jacobi_sp_dict, MF:20, 28-32]
+    void* coef[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    void* jac[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool stencil_set = false;
     size_t esize() const { return f64 ? 8 : 4; }
 };
 
@@ -80,6 +96,9 @@ struct mgx_solver {
     int use_graph = 1;              // MGX_GRAPH
     bool prof_mute = false;         // inside a stream capture: no events (they carry no time stamps there)
     int mixed_fuse = 1;             // mixed precision: u += s e and the residual in one pass (MGX_MIXED_FUSE)
+    // general per-level operators: dense inverse of the coarsest one (MF:18 coarsest_level_matrix, MF:63-72)
+    double *var_M = nullptr, *var_inv = nullptr, *var_pm = nullptr, *var_pi = nullptr;
+    bool var = false;               // cfg.op == MGX_OPERATOR_STENCIL5
     struct mgx_dist* dist = nullptr; // multi-GPU handle (cfg.n_gpus > 1 / mgx_create_rank): mgx_dist.hpp; no levels of its own
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -189,7 +208,8 @@ int alloc_level(mgx_solver* s, Level& l, int level, bool f64)
 
 void free_level(Level& l)
 {
-    for (void** p : {&l.u, &l.b, &l.tmp, &l.r}) {
+    for (void** p : {&l.u, &l.b, &l.tmp, &l.r, &l.coef[0], &l.coef[1], &l.coef[2], &l.coef[3], &l.coef[4],
+                     &l.jac[0], &l.jac[1], &l.jac[2], &l.jac[3], &l.jac[4]}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -255,6 +275,80 @@ void smooth_t(mgx_solver* s, Level& l, int mu)
                           s->cfg.omega, false, 1, l.N, 0, s->rows_per_chunk, s->fuse, s->stream, &parity, &launches);
     s->last_smooth_launches = launches;
     if (parity) std::swap(l.u, l.tmp);
+}
+
+// ---- general per-level operators (cfg.op = MGX_OPERATOR_STENCIL5; kernels in mgx_var.hpp) ---------------
+int var_alloc_level(mgx_solver* s, Level& l)
+{
+    for (void** p : {&l.coef[0], &l.coef[1], &l.coef[2], &l.coef[3], &l.coef[4], &l.jac[0], &l.jac[1], &l.jac[2], &l.jac[3], &l.jac[4]}) {
+        if (hipMalloc(p, l.bytes) != hipSuccess) return s->fail(MGX_ERR_ALLOC, "hipMalloc failed for the operator's coefficient arrays");
+        HIPCHK(s, hipMemsetAsync(*p, 0, l.bytes, s->stream));
+    }
+    return MGX_OK;
+}
+
+// the level's operator has been written into l.coef[]: build {D_inv, R_omega} (MF:28-32) and, on the coarsest
+// level with an exact bottom solve, the dense inverse (MF:63-72)
+template <typename T>
+int var_build_t(mgx_solver* s, Level& l)
+{
+    const dim3 blk(256), grd((l.N + 1 + 255) / 256, l.N + 1);
+    hipLaunchKernelGGL((k_var_build_jacobi<T>), grd, blk, 0, s->stream, (const T*)l.coef[0], (const T*)l.coef[1], (const T*)l.coef[2],
+                       (const T*)l.coef[3], (const T*)l.coef[4], (T*)l.jac[0], (T*)l.jac[1], (T*)l.jac[2], (T*)l.jac[3], (T*)l.jac[4],
+                       l.N, l.pitch, (T)s->cfg.omega);
+    if (l.L == s->cfg.coarsest_level && s->cfg.bottom == MGX_BOTTOM_EXACT) {
+        const int n = l.N - 1, NN = n * n;
+        hipLaunchKernelGGL((k_var_dense_fill<T>), dim3((NN + 255) / 256, NN), dim3(256), 0, s->stream, s->var_M, s->var_inv,
+                           (const T*)l.coef[0], (const T*)l.coef[1], (const T*)l.coef[2], (const T*)l.coef[3], (const T*)l.coef[4], n, l.pitch);
+        for (int k = 0; k < NN; ++k) {
+            hipLaunchKernelGGL(k_gj_prow, dim3((NN + 255) / 256), dim3(256), 0, s->stream, s->var_M, s->var_inv, s->var_pm, s->var_pi, NN, k);
+            hipLaunchKernelGGL(k_gj_elim, dim3(NN), dim3(256), 0, s->stream, s->var_M, s->var_inv, s->var_pm, s->var_pi, NN, k);
+        }
+    }
+    HIPCHK(s, hipGetLastError());
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    l.stencil_set = true;
+    for (auto& g : s->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    s->graphs.clear();       // (the kernels' coefficient pointers are unchanged, but a new operator is a new problem: recapture)
+    return MGX_OK;
+}
+int var_build(mgx_solver* s, Level& l) { return l.f64 ? var_build_t<double>(s, l) : var_build_t<float>(s, l); }
+
+// every level's operator must have been given before a schedule or operator runs
+int var_ready(mgx_solver* s, int lo, int hi)
+{
+    if (!s->var) return MGX_OK;
+    for (int l = lo; l <= hi; ++l)
+        if (!s->lv[l].stencil_set)
+            return s->fail(MGX_ERR_STATE, "operator of level " + std::to_string(l) + " not set (mgx_set_stencil / mgx_set_coefficient)");
+    return MGX_OK;
+}
+
+// MF:75-96: mu sweeps, one launch each, u <-> tmp
+template <typename T>
+void smooth_var_t(mgx_solver* s, Level& l, int mu)
+{
+    const T om = (T)s->cfg.omega;
+    const T rc = (T)(1.0 - (double)om);
+    const Launch g = make_launch(l.N, VecOf<T>::W, l.N - 1, 1);
+    for (int i = 0; i < mu; ++i) {
+        hipLaunchKernelGGL((k_jacobi_var<T>), dim3(g.blocks), dim3(kBlock), 0, s->stream, (const T*)l.u, (const T*)l.b, (T*)l.tmp,
+                           (const T*)l.jac[0], (const T*)l.jac[1], (const T*)l.jac[2], (const T*)l.jac[3], (const T*)l.jac[4],
+                           l.N, l.pitch, 1, l.N, g.strips, rc, om, l.rows);
+        std::swap(l.u, l.tmp);
+    }
+    s->last_smooth_launches = mu;
+}
+
+// MF:150-153: r = b - A u into `out` (MODE 0) or sum r^2 -> sum_dev (MODE 1)
+template <typename T, int MODE>
+void residual_var_t(mgx_solver* s, const Level& l, const void* u, const void* b, void* out)
+{
+    const Launch g = make_launch(l.N, VecOf<T>::W, l.N - 1, 1);
+    hipLaunchKernelGGL((k_residual_var<T, MODE>), dim3(g.blocks), dim3(kBlock), 0, s->stream, (const T*)u, (const T*)b, (T*)out,
+                       s->partial, (const T*)l.coef[0], (const T*)l.coef[1], (const T*)l.coef[2], (const T*)l.coef[3],
+                       (const T*)l.coef[4], l.N, l.pitch, 1, l.N, g.strips, l.rows);
+    if (MODE == 1) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kReduceThreads), 0, s->stream, s->partial, g.blocks, s->sum_dev);
 }
 
 // ---- planning the passes of a folded smoothing block ------------------------------------------
@@ -403,6 +497,8 @@ bool smooth_folded_t(mgx_solver* s, Level& l, int mu, const Level* coarse, bool 
 bool fold_eligible(const mgx_solver* s, const Level& l, int mu, bool pre = false, int post = 1)
 {
     if (!s->fold || mu < 1 || mu > 64) return false;
+    // general operators have no fused / folded kernels; the folded restriction is full weighting
+    if (s->var || (post == 1 && s->cfg.restrict_mode >= MGX_RESTRICT_INJECT)) return false;
     if (tile_level(s, l)) return true;
     if (l.N < s->fuse.min_n) return false;
     const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
@@ -462,7 +558,8 @@ void smooth(mgx_solver* s, int level, int mu)
     Level& l = s->lv[level];
     const bool fine = (level == s->cfg.finest_level);
     Prof p(s, fine ? MGX_PROF_SMOOTH_FINE : MGX_PROF_COARSE, mu);
-    if (l.f64) smooth_t<double>(s, l, mu); else smooth_t<float>(s, l, mu);
+    if (s->var) { if (l.f64) smooth_var_t<double>(s, l, mu); else smooth_var_t<float>(s, l, mu); }       // MF:75-96
+    else if (l.f64) smooth_t<double>(s, l, mu); else smooth_t<float>(s, l, mu);
     p.set(s->last_smooth_launches, mu);
     if (fine) s->fine_updates += (double)mu * (double)(l.N - 1) * (double)(l.N - 1);
 }
@@ -475,6 +572,33 @@ void restrict_level(mgx_solver* s, int level, bool fused, bool zero_guess)
     const bool fine = (level == s->cfg.finest_level);
     Prof p(s, fine ? MGX_PROF_RESTRICT_FINE : MGX_PROF_COARSE, 1);
     const int rpc = s->rows_per_chunk;
+    const int mode = s->cfg.restrict_mode;
+    if (s->var || mode >= MGX_RESTRICT_INJECT) {
+        // general operator and / or injection (MF:122-130): the residual is formed first (MF:150-153; f.r was
+        // allocated with the handle), then restricted by full weighting (PS:531-546) or injected
+        const void* src = f.b;
+        if (fused) {
+            if (s->var) { if (f.f64) residual_var_t<double, 0>(s, f, f.u, f.b, f.r); else residual_var_t<float, 0>(s, f, f.u, f.b, f.r); }
+            else if (f.f64) launch_residual<double, 0>((const double*)f.u, (const double*)f.b, f.r, f.pitch, nullptr, nullptr, 1.0, f.N, f.pitch, 1, f.N, rpc, s->stream, -1, f.rows);
+            else launch_residual<float, 0>((const float*)f.u, (const float*)f.b, f.r, f.pitch, nullptr, nullptr, 1.0, f.N, f.pitch, 1, f.N, rpc, s->stream, -1, f.rows);
+            src = f.r;
+        }
+        if (mode >= MGX_RESTRICT_INJECT) {
+            const double w = (mode == MGX_RESTRICT_INJECT4) ? 4.0 : 1.0;
+            const dim3 blk(256), grd((c.N + 255) / 256, c.N - 1);
+            if (f.f64) hipLaunchKernelGGL((k_restrict_inject<double>), grd, blk, 0, s->stream, (const double*)src, (double*)c.b,
+                                          zero_guess ? (double*)c.u : nullptr, c.N, f.pitch, c.pitch, w);
+            else hipLaunchKernelGGL((k_restrict_inject<float>), grd, blk, 0, s->stream, (const float*)src, (float*)c.b,
+                                    zero_guess ? (float*)c.u : nullptr, c.N, f.pitch, c.pitch, (float)w);
+        } else if (f.f64) {
+            launch_restrict<double>((const double*)f.u, (const double*)src, (double*)c.b, zero_guess ? (double*)c.u : nullptr, f.N, f.pitch, c.pitch,
+                                    1, c.N, 0, mode, false, rpc, s->stream);
+        } else {
+            launch_restrict<float>((const float*)f.u, (const float*)src, (float*)c.b, zero_guess ? (float*)c.u : nullptr, f.N, f.pitch, c.pitch,
+                                   1, c.N, 0, mode, false, rpc, s->stream);
+        }
+        return;
+    }
     if (f.f64)
         launch_restrict<double>((const double*)f.u, (const double*)f.b, (double*)c.b, zero_guess ? (double*)c.u : nullptr,
                                 f.N, f.pitch, c.pitch, 1, c.N, 0, s->cfg.restrict_mode, fused, rpc, s->stream);
@@ -500,6 +624,12 @@ void bottom_solve(mgx_solver* s)
 {
     Level& l = s->lv[s->cfg.coarsest_level];
     Prof p(s, (l.L == s->cfg.finest_level) ? MGX_PROF_SMOOTH_FINE : MGX_PROF_COARSE, 4);
+    if (s->var) {                                                        // MF:63-72: x = A^-1 b, A^-1 built at set-up
+        const int n = l.N - 1;
+        if (l.f64) hipLaunchKernelGGL((k_var_dense_solve<double>), dim3((n * n + 63) / 64), dim3(64), 0, s->stream, s->var_inv, (const double*)l.b, (double*)l.u, n, l.pitch);
+        else hipLaunchKernelGGL((k_var_dense_solve<float>), dim3((n * n + 63) / 64), dim3(64), 0, s->stream, s->var_inv, (const float*)l.b, (float*)l.u, n, l.pitch);
+        return;
+    }
     if (l.f64) s->bottom.solve<double>((const double*)l.b, (double*)l.u, l.pitch, s->stream);
     else s->bottom.solve<float>((const float*)l.b, (float*)l.u, l.pitch, s->stream);
 }
@@ -576,6 +706,9 @@ int enqueue_norm(mgx_solver* s, const Level& l, const void* u, const void* b, in
         Prof p(s, cls, 1);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kReduceThreads), 0, s->stream, s->partial, s->norm_blocks_ready,
                            s->sum_dev);
+    } else if (s->var) {
+        Prof p(s, cls, 2);
+        if (l.f64) residual_var_t<double, 1>(s, l, u, b, nullptr); else residual_var_t<float, 1>(s, l, u, b, nullptr);
     } else {
         Prof p(s, cls, 2);
         if (l.f64)
@@ -854,6 +987,7 @@ int mgx_config_default(mgx_config* c)
     c->cut_level = 0;
     for (int i = 0; i < MGX_MAX_GPUS; ++i) c->devices[i] = -1;
     c->arith = MGX_ARITH_SEPARATE;
+    c->op = MGX_OPERATOR_POISSON;
     return MGX_OK;
 }
 
@@ -889,16 +1023,27 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
     if (cfg->coarsest_level < 2 || cfg->finest_level < cfg->coarsest_level || cfg->finest_level > 15 ||
         cfg->mu0 < 0 || cfg->mu1 < 0 || cfg->mu2 < 0 || !(cfg->omega > 0.0 && cfg->omega < 2.0) ||
         cfg->smoother < 0 || cfg->smoother > 1 || cfg->dtype < 0 || cfg->dtype > 2 ||
-        cfg->schedule < 0 || cfg->schedule > 1 || cfg->restrict_mode < 0 || cfg->restrict_mode > 1 ||
-        cfg->bottom < 0 || cfg->bottom > 1 || cfg->arith < 0 || cfg->arith > 1) {
+        cfg->schedule < 0 || cfg->schedule > 1 || cfg->restrict_mode < 0 || cfg->restrict_mode > MGX_RESTRICT_INJECT4 ||
+        cfg->bottom < 0 || cfg->bottom > 1 || cfg->arith < 0 || cfg->arith > 1 || cfg->op < 0 || cfg->op > 1) {
         g_create_error = "invalid configuration";
         return MGX_ERR_INVALID;
     }
-    if (cfg->bottom == MGX_BOTTOM_EXACT && cfg->coarsest_level > 8) {
-        g_create_error = "exact bottom solve supports coarsest_level <= 8";
+    const bool var = (cfg->op == MGX_OPERATOR_STENCIL5);
+    if (cfg->bottom == MGX_BOTTOM_EXACT && cfg->coarsest_level > (var ? 5 : 8)) {
+        g_create_error = var ? "exact bottom solve of a general operator (dense inverse) supports coarsest_level <= 5"
+                             : "exact bottom solve supports coarsest_level <= 8";
+        return MGX_ERR_INVALID;
+    }
+    if (var && (cfg->dtype == MGX_DTYPE_MIXED || cfg->smoother != MGX_SMOOTHER_JACOBI || cfg->arith != MGX_ARITH_SEPARATE || cfg->n_gpus > 1)) {
+        g_create_error = "MGX_OPERATOR_STENCIL5: dtype F64 or F32, Jacobi (MF:75-96), arith SEPARATE, one GPU";
+        return MGX_ERR_INVALID;
+    }
+    if (cfg->restrict_mode >= MGX_RESTRICT_INJECT && (cfg->n_gpus > 1 || cfg->dtype == MGX_DTYPE_MIXED)) {
+        g_create_error = "injection restriction (MF:122-130): single-GPU handles of dtype F64 or F32";
         return MGX_ERR_INVALID;
     }
     if (cfg->n_gpus > 1) return mgx_create_rank(cfg, -1, 1, nullptr, nullptr, out);
+    log_runtime_libs("mgx_create");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
         g_create_error = "no usable HIP device (libmgx has no CPU fallback)";
@@ -910,6 +1055,7 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
     if (!s) { g_create_error = "out of host memory"; return MGX_ERR_ALLOC; }
     s->cfg = *cfg;
     s->mixed = (cfg->dtype == MGX_DTYPE_MIXED);
+    s->var = var;
     s->work_f64 = (cfg->dtype == MGX_DTYPE_F64);
     s->rows_per_chunk = env_int("MGX_ROWS", 0);
     s->fuse = fuse_cfg();
@@ -924,6 +1070,24 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
     for (int l = cfg->coarsest_level; l <= cfg->finest_level; ++l)
         if ((rc = alloc_level(s, s->lv[l], l, s->work_f64)) != MGX_OK) return bail(rc);
     if (s->mixed && (rc = alloc_level(s, s->fine64, cfg->finest_level, true)) != MGX_OK) return bail(rc);
+    if (var || cfg->restrict_mode >= MGX_RESTRICT_INJECT) {
+        // these cycles form the residual as a grid (MF:150-153) before restricting it: allocate it now (nothing may be
+        // allocated while a cycle is being captured into a graph)
+        for (int l = cfg->coarsest_level + 1; l <= cfg->finest_level; ++l)
+            if ((rc = ensure_r(s, s->lv[l])) != MGX_OK) return bail(rc);
+    }
+    if (var) {
+        for (int l = cfg->coarsest_level; l <= cfg->finest_level; ++l)
+            if ((rc = var_alloc_level(s, s->lv[l])) != MGX_OK) return bail(rc);
+        if (cfg->bottom == MGX_BOTTOM_EXACT) {
+            const size_t NN = (size_t)((1 << cfg->coarsest_level) - 1) * ((1 << cfg->coarsest_level) - 1);
+            if (hipMalloc(&s->var_M, NN * NN * sizeof(double)) != hipSuccess || hipMalloc(&s->var_inv, NN * NN * sizeof(double)) != hipSuccess ||
+                hipMalloc(&s->var_pm, NN * sizeof(double)) != hipSuccess || hipMalloc(&s->var_pi, NN * sizeof(double)) != hipSuccess) {
+                s->err = "allocation of the coarsest operator's dense inverse failed";
+                return bail(MGX_ERR_ALLOC);
+            }
+        }
+    }
     s->mixed_fuse = env_int("MGX_MIXED_FUSE", 1);
     // fine64.tmp: the out-of-place target of the fused update + residual pass
     if (s->mixed && !s->mixed_fuse) { (void)hipFree(s->fine64.tmp); s->fine64.tmp = nullptr; }
@@ -944,7 +1108,7 @@ int mgx_create(const mgx_config* cfg, mgx_handle* out)
             return bail(MGX_ERR_ALLOC);
         }
     }
-    if (cfg->bottom == MGX_BOTTOM_EXACT) {
+    if (cfg->bottom == MGX_BOTTOM_EXACT && !var) {
         if (s->bottom.init((1 << cfg->coarsest_level) - 1) != hipSuccess) {
             s->err = "bottom solver allocation failed";
             return bail(MGX_ERR_ALLOC);
@@ -966,6 +1130,7 @@ int mgx_destroy(mgx_handle s)
     if (s->partial) (void)hipFree(s->partial);
     if (s->sum_dev) (void)hipFree(s->sum_dev);
     if (s->sum_host) (void)hipHostFree(s->sum_host);
+    for (double* p : {s->var_M, s->var_inv, s->var_pm, s->var_pi}) if (p) (void)hipFree(p);
     for (auto& g : s->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (auto& p : s->ev_used) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : s->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -1126,6 +1291,59 @@ int mgx_fill_guess_random(mgx_handle s, uint64_t seed)
     return MGX_OK;
 }
 
+// ---- general per-level operators (MF:16-41) ---------------------------------------------------
+int mgx_set_stencil(mgx_handle s, int level, const void* c, const void* n, const void* so, const void* w, const void* e, size_t count)
+{
+    if (!s || !c || !n || !so || !w || !e) return MGX_ERR_INVALID;
+    NO_DIST(s)
+    if (!s->var) return s->fail(MGX_ERR_STATE, "handle was created with op = MGX_OPERATOR_POISSON (the constant stencil needs no coefficients)");
+    if (!level_ok(s, level)) return s->fail(MGX_ERR_INVALID, "level out of range");
+    Level& l = s->lv[level];
+    const void* src[5] = {c, n, so, w, e};
+    for (int q = 0; q < 5; ++q) {
+        int rc = copy_in(s, l, l.coef[q], src[q], count);
+        if (rc) return rc;
+    }
+    return var_build(s, l);
+}
+
+int mgx_set_coefficient(mgx_handle s, const double* a_nodes, size_t count)
+{
+    if (!s || !a_nodes) return MGX_ERR_INVALID;
+    NO_DIST(s)
+    if (!s->var) return s->fail(MGX_ERR_STATE, "handle was created with op = MGX_OPERATOR_POISSON");
+    const int Lf = s->cfg.finest_level, Nf = 1 << Lf;
+    if (count != (size_t)(Nf + 1) * (size_t)(Nf + 1)) return s->fail(MGX_ERR_INVALID, "coefficient must hold (N + 1)^2 nodal values, N = 2^finest_level");
+    double* dev = nullptr;
+    if (hipMalloc(&dev, count * sizeof(double)) != hipSuccess) return s->fail(MGX_ERR_ALLOC, "hipMalloc failed for the nodal coefficient");
+    int rc = MGX_OK;
+    if (hipMemcpyAsync(dev, a_nodes, count * sizeof(double), hipMemcpyHostToDevice, s->stream) != hipSuccess) rc = s->fail(MGX_ERR_HIP, "copy of the nodal coefficient failed");
+    for (int lv = s->cfg.coarsest_level; lv <= Lf && rc == MGX_OK; ++lv) {
+        Level& l = s->lv[lv];
+        const dim3 blk(256), grd((l.N + 1 + 255) / 256, l.N + 1);
+        const int q = 1 << (Lf - lv);
+        if (l.f64) hipLaunchKernelGGL((k_var_from_nodes<double>), grd, blk, 0, s->stream, dev, Nf, q, (double*)l.coef[0], (double*)l.coef[1],
+                                      (double*)l.coef[2], (double*)l.coef[3], (double*)l.coef[4], l.N, l.pitch);
+        else hipLaunchKernelGGL((k_var_from_nodes<float>), grd, blk, 0, s->stream, dev, Nf, q, (float*)l.coef[0], (float*)l.coef[1],
+                                (float*)l.coef[2], (float*)l.coef[3], (float*)l.coef[4], l.N, l.pitch);
+        rc = var_build(s, l);
+    }
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipFree(dev);
+    return rc;
+}
+
+int mgx_get_stencil(mgx_handle s, int level, int which, void* dst, size_t count)
+{
+    if (!s || !dst) return MGX_ERR_INVALID;
+    NO_DIST(s)
+    if (!s->var) return s->fail(MGX_ERR_STATE, "handle was created with op = MGX_OPERATOR_POISSON");
+    if (!level_ok(s, level) || which < 0 || which > 9) return s->fail(MGX_ERR_INVALID, "level or array selector out of range");
+    Level& l = s->lv[level];
+    if (!l.stencil_set) return s->fail(MGX_ERR_STATE, "operator of this level not set");
+    return copy_out(s, l, which < 5 ? l.coef[which] : l.jac[which - 5], dst, count);
+}
+
 // ---- operators ------------------------------------------------------------------------
 // On a MIXED handle the finest level exists twice: the double u, b the accessors address
 // (mgx_set_level / mgx_get_level / mgx_set_rhs ...) and the float correction / residual scratch of
@@ -1142,7 +1360,8 @@ int mgx_fill_guess_random(mgx_handle s, uint64_t seed)
     NO_DIST(s)                                                                            \
     if (level < (lvl_min) || level > s->cfg.finest_level)                                 \
         return s->fail(MGX_ERR_INVALID, "level out of range for this operator");          \
-    MIXED_GUARD(level)
+    MIXED_GUARD(level)                                                                    \
+    if (int vr__ = var_ready(s, s->cfg.coarsest_level, level)) return vr__;
 
 #define OP_EPILOGUE                                                                       \
     HIPCHK(s, hipGetLastError());                                                         \
@@ -1163,7 +1382,9 @@ int mgx_residual(mgx_handle s, int level)
     Level& l = s->lv[level];
     int rc = ensure_r(s, l);
     if (rc) return rc;
-    if (l.f64)
+    if (s->var) {
+        if (l.f64) residual_var_t<double, 0>(s, l, l.u, l.b, l.r); else residual_var_t<float, 0>(s, l, l.u, l.b, l.r);
+    } else if (l.f64)
         launch_residual<double, 0>((const double*)l.u, (const double*)l.b, l.r, l.pitch, nullptr, nullptr, 1.0, l.N,
                                    l.pitch, 1, l.N, s->rows_per_chunk, s->stream, -1, l.rows);
     else
@@ -1206,6 +1427,7 @@ int mgx_bottom_solve(mgx_handle s)
     NO_DIST(s)
     if (s->cfg.bottom != MGX_BOTTOM_EXACT) return s->fail(MGX_ERR_STATE, "handle was created with bottom = SMOOTH");
     MIXED_GUARD(s->cfg.coarsest_level)
+    if (int vr = var_ready(s, s->cfg.coarsest_level, s->cfg.coarsest_level)) return vr;
     bottom_solve(s);
     OP_EPILOGUE
 }
@@ -1218,6 +1440,7 @@ int mgx_residual_norm(mgx_handle s, int level, double* out)
         if (level != s->cfg.finest_level) return s->fail(MGX_ERR_STATE, "multi-GPU handles: residual norm of the finest level only");
         return dist_norm(s, s->dist, out);
     }
+    if (int vr = var_ready(s, level, level)) return vr;
     void* gu = nullptr; void* gb = nullptr;
     Level* l = pick(s, level, MGX_VEC_U, &gu);
     (void)pick(s, level, MGX_VEC_B, &gb);
@@ -1242,6 +1465,7 @@ int mgx_vcycle_zero(mgx_handle s)
     if (!s) return MGX_ERR_INVALID;
     NO_DIST(s)
     MIXED_GUARD(s->cfg.finest_level)
+    if (int vr = var_ready(s, s->cfg.coarsest_level, s->cfg.finest_level)) return vr;
     double unused = 0.0;
     int rc = cycle_body(s, false, true, &unused);
     if (rc) return rc;
@@ -1256,6 +1480,7 @@ int mgx_fmg(mgx_handle s)
         return rc ? rc : dist_sync(s, s->dist);
     }
     MIXED_GUARD(s->cfg.finest_level)
+    if (int vr = var_ready(s, s->cfg.coarsest_level, s->cfg.finest_level)) return vr;
     int rc = fmg(s);
     if (rc) return rc;
     OP_EPILOGUE
@@ -1266,6 +1491,7 @@ int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double
 {
     if (!s || max_cycles < 0 || !(tol >= 0.0)) return MGX_ERR_INVALID;
     if (s->dist) return dist_solve(s, s->dist, tol, max_cycles, stats, history, history_cap);
+    if (int vr = var_ready(s, s->cfg.coarsest_level, s->cfg.finest_level)) return vr;
     const int L = s->cfg.finest_level;
     const bool do_fmg = (s->cfg.schedule == MGX_SCHEDULE_FMG);
     std::vector<double> hist;
@@ -1680,6 +1906,7 @@ int mgx_create_rank(const mgx_config* cfg, int rank, int world, const void* rccl
         g_create_error = "invalid configuration";
         return MGX_ERR_INVALID;
     }
+    log_runtime_libs("mgx_create_rank");
     mgx_solver* s = new (std::nothrow) mgx_solver();
     if (!s) { g_create_error = "out of host memory"; return MGX_ERR_ALLOC; }
     s->cfg = *cfg;
@@ -1687,6 +1914,37 @@ int mgx_create_rank(const mgx_config* cfg, int rank, int world, const void* rccl
     if (rc != MGX_OK) { g_create_error = s->err; mgx_destroy(s); return rc; }
     *out = s;
     return MGX_OK;
+}
+
+// Which ROCm runtime libraries this process has mapped (/proc/self/maps): libmgx is built against /opt/rocm
+// (RUNPATH), and a host application that loaded another copy of libamdhip64 / libhsa-runtime64 / librccl
+// first (the torch wheel bundles its own, with the same SONAMEs) would run this library's code objects on
+// THAT stack.  One path per line; returns the number of bytes written (without the terminator), < 0 on error.
+int mgx_runtime_libs(char* buf, size_t cap)
+{
+    if (!buf || cap == 0) return -1;
+    buf[0] = 0;
+    FILE* fh = std::fopen("/proc/self/maps", "r");
+    if (!fh) return -1;
+    std::vector<std::string> seen;
+    char line[4096];
+    while (std::fgets(line, sizeof line, fh)) {
+        const char* path = std::strchr(line, '/');
+        if (!path) continue;
+        std::string p(path);
+        while (!p.empty() && (p.back() == '\n' || p.back() == ' ')) p.pop_back();
+        const char* names[] = {"libamdhip64", "libhsa-runtime64", "librccl", "libmgx", "libhiprtc", "libamd_comgr"};
+        bool want = false;
+        for (const char* n : names) want = want || p.find(n) != std::string::npos;
+        if (!want || std::find(seen.begin(), seen.end(), p) != seen.end()) continue;
+        seen.push_back(p);
+    }
+    std::fclose(fh);
+    std::string out;
+    for (const auto& p : seen) { out += p; out += '\n'; }
+    if (out.size() + 1 > cap) out.resize(cap - 1);
+    std::memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)out.size();
 }
 
 int mgx_rccl_unique_id(void* out128)

@@ -53,6 +53,7 @@ struct mgx_dist {
     int rank = -1, world = 1;                // rank >= 0: one slab per process
     bool use_rccl = false;
     ncclComm_t comm = nullptr;
+    bool comm_broken = false;                // an RCCL call failed: the communicator is aborted, not destroyed
     bool have_ext = false;
     mgx_transport ext{};
     long exchanges = 0;
@@ -79,8 +80,10 @@ thread_local std::string g_plan_error;
 #define NCHK(s, expr)                                                                    \
     do {                                                                                 \
         ncclResult_t r__ = (expr);                                                       \
-        if (r__ != ncclSuccess)                                                          \
+        if (r__ != ncclSuccess) {                                                        \
+            if ((s)->dist) (s)->dist->comm_broken = true;                                \
             return (s)->fail(MGX_ERR_HIP, std::string(#expr) + ": " + ncclGetErrorString(r__)); \
+        }                                                                                \
     } while (0)
 
 DistPlanCfg plan_cfg_of(const mgx_config& c, int P, int g, int cut, bool fold, bool deep)
@@ -155,7 +158,8 @@ void dist_free(mgx_dist* d)
     }
     for (auto& p : d->ev_used) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : d->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    if (d->comm) (void)ncclCommDestroy(d->comm);
+    // ncclCommDestroy waits for the peers; after a failed collective they may never come: abort instead
+    if (d->comm) (void)(d->comm_broken ? ncclCommAbort(d->comm) : ncclCommDestroy(d->comm));
     delete d;
 }
 
@@ -169,14 +173,16 @@ int dist_alloc_slab(mgx_solver* s, mgx_dist* d, DistSlab& sl)
     const int dt = d->f64 ? MGX_DTYPE_F64 : MGX_DTYPE_F32;
     long scratch = 0;
     for (const mgx_dist_level& g : sl.plan.geom) {
-        DistLevelBuf lb;
+        // (the level is registered before its arrays are allocated: dist_free then releases whatever a
+        // failing hipMalloc left behind)
+        sl.lv.emplace_back();
+        DistLevelBuf& lb = sl.lv.back();
         lb.pitch = level_pitch(g.level, dt);
         lb.bytes = (size_t)g.rows * (size_t)lb.pitch * d->es;
         for (void** p : {&lb.u, &lb.b, &lb.tmp}) {
-            if (hipMalloc(p, lb.bytes) != hipSuccess) return s->fail(MGX_ERR_ALLOC, "hipMalloc failed for a slab level");
+            if (hipMalloc(p, lb.bytes) != hipSuccess) { *p = nullptr; return s->fail(MGX_ERR_ALLOC, "hipMalloc failed for a slab level"); }
             DCHK(s, hipMemsetAsync(*p, 0, lb.bytes, sl.st));
         }
-        sl.lv.push_back(lb);
         const mgx_slab ms{g.level, dt, g.rows, g.row0, 0};
         scratch = std::max(scratch, mgx_slab_scratch_doubles(&ms));
     }
@@ -259,6 +265,9 @@ int dist_create(mgx_solver* s, const mgx_config* cfg, int rank, int world, const
             ncclUniqueId id;
             std::memcpy(&id, rccl_id, sizeof(id) < 128 ? sizeof(id) : 128);
             DCHK(s, hipSetDevice(d->slabs[0].device));
+            // RCCL checks hipGetLastError() after its own launches: an error some EARLIER call of this thread left
+            // behind (the host application's, or a refused call of ours) must not be taken for RCCL's
+            (void)hipGetLastError();
             NCHK(s, ncclCommInitRank(&d->comm, world, id, rank));
             d->use_rccl = true;
         }
@@ -371,11 +380,17 @@ int dist_exchange(mgx_solver* s, mgx_dist* d, const mgx_dist_op& o, bool on_comm
         if (d->use_rccl) {
             // one group per exchange: the sends and receives of both neighbours progress together
             NCHK(s, ncclGroupStart());
-            for (int i = 0; i < n; ++i) {
-                if (x[i].send) NCHK(s, ncclSend(x[i].ptr, x[i].bytes, ncclChar, x[i].peer, d->comm, xs(sl)));
-                else NCHK(s, ncclRecv(x[i].ptr, x[i].bytes, ncclChar, x[i].peer, d->comm, xs(sl)));
+            ncclResult_t gr = ncclSuccess;
+            const char* what = "";
+            for (int i = 0; i < n && gr == ncclSuccess; ++i) {
+                if (x[i].send) { gr = ncclSend(x[i].ptr, x[i].bytes, ncclChar, x[i].peer, d->comm, xs(sl)); what = "ncclSend"; }
+                else { gr = ncclRecv(x[i].ptr, x[i].bytes, ncclChar, x[i].peer, d->comm, xs(sl)); what = "ncclRecv"; }
             }
-            NCHK(s, ncclGroupEnd());
+            // the group is closed whatever happened inside it (a return between Start and End would leave
+            // every later RCCL call of this thread inside an open group)
+            const ncclResult_t ge = ncclGroupEnd();
+            if (gr != ncclSuccess) { d->comm_broken = true; return s->fail(MGX_ERR_HIP, std::string(what) + ": " + ncclGetErrorString(gr)); }
+            if (ge != ncclSuccess) { d->comm_broken = true; return s->fail(MGX_ERR_HIP, std::string("ncclGroupEnd: ") + ncclGetErrorString(ge)); }
         } else if (d->have_ext) {
             if (d->ext.sendrecv(d->ext.ctx, n, x, (void*)xs(sl)) != 0) return s->fail(MGX_ERR_HIP, "transport sendrecv failed");
         }

@@ -1,24 +1,26 @@
 """bench.py's N > 1 leg: one process per GPU, each rank a libmgx multi-GPU handle
 (mgx_create_rank: csrc/mgx_dist.hpp) owning one row slab of BASELINE config 4's grid; halo rows move by
-RCCL send/recv over xGMI on the slab's stream (built-in transport).  torch.distributed (gloo) is only
-the control plane here: it hands rank 0's ncclUniqueId to the other ranks, and carries the barrier and
-the max-over-ranks of the timed region the bench contract asks for.
+RCCL send/recv over xGMI on the slab's stream (built-in transport).  The control plane is the TCP store
+of rendezvous.py: it hands rank 0's ncclUniqueId to the other ranks and carries the barrier and the
+max-over-ranks of the timed region the bench contract asks for.  No torch in a rank process: libmgx runs
+on the ROCm stack it was built against (the line reports the mapped libraries, `runtime_libs`).
 
-Rehearsal on a 1-GPU box (RCCL refuses two ranks on one device): MGX_DIST_SINGLE_DEVICE=1
-MGX_DIST_BACKEND=gloo puts every rank on device 0 and swaps the RCCL transport for the host-staged
-gloo one (transport.py) - same C++ executor, plans and kernels; the timing then means nothing."""
+If the RCCL transport fails on any rank the job reports `value: null` with the error and exits non-zero:
+a host-staged number is never printed under an N-GPU label.  Rehearsal on a 1-GPU box (RCCL refuses two
+ranks on one device) is an explicit opt-in: MGX_DIST_SINGLE_DEVICE=1 MGX_DIST_BACKEND=staged puts every
+rank on device 0 and swaps the RCCL transport for the host-staged one (transport.py) - same C++
+executor, plans and kernels; the line then carries `transport: "staged"` and its timing means nothing."""
 from __future__ import annotations
 
 import json
 import os
+import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import torch
-import torch.distributed as dist
-
 from . import binding as B
+from .rendezvous import Store
 from .transport import StagedTransport, broadcast_rccl_id
 
 HBM_PEAK_GBS = 8000.0
@@ -29,7 +31,8 @@ def single_gpu_reference(args, L, steps, device):
     (untimed part of the job; gives the like-for-like strong-scaling baseline)"""
     mg = B.Multigrid(finest_level=L, coarsest_level=min(args.coarsest, L), mu0=0, mu1=args.mu1, mu2=args.mu2,
                      omega=args.omega, smoother=B.SMOOTHER_RBGS if args.smoother == "rbgs" else B.SMOOTHER_JACOBI,
-                     dtype=B.DTYPE_F32 if args.dtype == "f32" else B.DTYPE_F64, schedule=B.SCHEDULE_V, device=device)
+                     dtype=B.DTYPE_F32 if args.dtype == "f32" else B.DTYPE_F64, schedule=B.SCHEDULE_V, device=device,
+                     arith=B.ARITH_FMA if getattr(args, "arith", "fma") == "fma" else B.ARITH_SEPARATE)
     try:
         mg.fill_rhs(1, 0.0)
         mg.fill_guess_random(12345)
@@ -44,48 +47,49 @@ def single_gpu_reference(args, L, steps, device):
         mg.close()
 
 
+def null_line(args, world, error, transport):
+    L = args.level
+    return {"metric": "fine_grid_stencil_updates_per_sec", "value": None, "unit": "updates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic", "transport": transport,
+            "config": {"workload": f"2D Poisson {1 << L}^2, row slabs over {world} GPUs"}, "error": error}
+
+
 def run(args, emit=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    backend = os.environ.get("MGX_DIST_BACKEND", "nccl")          # data plane: "nccl" = the built-in RCCL transport
+    backend = os.environ.get("MGX_DIST_BACKEND", "rccl")          # data plane: "rccl" (= "nccl") | "staged" (= "gloo"), explicit
+    backend = {"nccl": "rccl", "gloo": "staged"}.get(backend, backend)
+    if backend not in ("rccl", "staged"):
+        raise SystemExit(f"MGX_DIST_BACKEND={backend!r}: expected rccl or staged")
     rehearsal = bool(os.environ.get("MGX_DIST_SINGLE_DEVICE"))
     if rehearsal:
         local = 0
     if args.dtype == "mixed":
         raise SystemExit("--dtype mixed is a single-GPU configuration")
-    # control plane
-    dist.init_process_group("gloo")
-    assert dist.get_world_size() == world and world == args.gpus, (dist.get_world_size(), world, args.gpus)
+    out_line = emit if emit is not None else (lambda o: print(json.dumps(o), flush=True))
+    # control plane (every blocking call has a deadline: rendezvous.py)
+    store = Store(rank, world)
+    assert world == args.gpus, (world, args.gpus)
     L = args.level
     n = (1 << L) - 1
     cfg = dict(finest_level=L, coarsest_level=min(args.coarsest, L), mu0=0, mu1=args.mu1, mu2=args.mu2, omega=args.omega,
                smoother=B.SMOOTHER_RBGS if args.smoother == "rbgs" else B.SMOOTHER_JACOBI,
-               dtype=B.DTYPE_F32 if args.dtype == "f32" else B.DTYPE_F64, schedule=B.SCHEDULE_V, device=local, profile=1)
+               dtype=B.DTYPE_F32 if args.dtype == "f32" else B.DTYPE_F64, schedule=B.SCHEDULE_V, device=local, profile=1,
+               arith=B.ARITH_FMA if getattr(args, "arith", "fma") == "fma" else B.ARITH_SEPARATE)
     ref = None
     if rank == 0:
         ref = single_gpu_reference(args, L, max(1, min(args.steps, 5)), local)
-    dist.barrier()
-    if rehearsal:
-        # every rank on ONE device: each loads the code object and runs its first kernel alone (a rank's very
-        # first launch once died with an illegal-instruction fault while the others were doing the same)
-        for r in range(world):
-            if r == rank:
-                with B.Multigrid(finest_level=6, coarsest_level=5, schedule=B.SCHEDULE_V, device=local) as warm:
-                    warm.fill_rhs(1, 0.0)
-                    warm.synchronize()
-            dist.barrier()
+    store.barrier()
     transport = None
     mg = None
-    wire = None
-    if backend == "nccl":
-        # the built-in RCCL transport; one warm-up cycle proves every collective it uses before anything
-        # is timed.  If ANY rank fails (never seen on this code, but RCCL with > 1 rank has only ever run
-        # on the driver's node), every rank drops to the host-staged transport and the line says so:
-        # a slower honest number instead of none.
+    if backend == "rccl":
+        # the built-in RCCL transport; one warm-up cycle proves every collective it uses before anything is
+        # timed.  A failure on ANY rank ends the job with value: null (never a host-staged number under this label).
         err = ""
         try:
-            rccl_id = broadcast_rccl_id()
+            rccl_id = broadcast_rccl_id(store)
             mg = B.Multigrid.rank(rank, world, rccl_id=rccl_id, **cfg)
             mg.fill_rhs(1, 0.0)
             mg.fill_guess_random(12345)
@@ -93,33 +97,25 @@ def run(args, emit=None):
             mg.synchronize()
         except Exception as e:      # noqa: BLE001 - whatever it is, the other ranks must hear of it
             err = f"rank {rank}: {type(e).__name__}: {e}"
-        bad = torch.tensor([1 if err else 0], dtype=torch.int64)
-        dist.all_reduce(bad)
-        if int(bad.item()) == 0:
-            wire = "RCCL send/recv (built-in transport, ncclCommInitRank over xGMI)"
-        else:
-            if err:
-                import sys
-                sys.stderr.write(f"dist_bench: RCCL transport failed ({err}); falling back to host-staged halos\n")
-            if mg is not None:
-                try:
-                    mg.close()
-                except Exception:   # noqa: BLE001
-                    pass
-                mg = None
-            backend = "gloo"
-            wire = f"gloo with host-staged halos (FALLBACK: the RCCL transport failed on {int(bad.item())} rank(s))"
-    if mg is None:
-        transport = StagedTransport()
+        errs = [e.decode() for e in store.allgather(err.encode()) if e]
+        if errs:
+            if rank == 0:
+                out_line(null_line(args, world, "RCCL transport failed: " + " | ".join(errs), "rccl"))
+            sys.stderr.write(f"dist_bench: RCCL transport failed ({'; '.join(errs)})\n")
+            # no mgx_destroy on a communicator whose peers may be gone (it is aborted at process exit)
+            os._exit(4)
+        wire = "RCCL send/recv (built-in transport, ncclCommInitRank over xGMI)"
+    else:
+        transport = StagedTransport(store)
         mg = B.Multigrid.rank(rank, world, transport=transport.struct, **cfg)
-        wire = wire or f"{backend} with host-staged halos (rehearsal transport)"
+        wire = "host-staged halos through the TCP store (rehearsal transport, explicit MGX_DIST_BACKEND=staged)"
     plan = B.Plan(world, rank, **{k: v for k, v in cfg.items() if k not in ("device", "profile")})
     cut = plan.cut
     halo = plan.level(L).halo
 
     def barrier():
         mg.synchronize()
-        dist.barrier()
+        store.barrier()
 
     mg.fill_rhs(1, 0.0)
     mg.fill_guess_random(12345)
@@ -134,18 +130,14 @@ def run(args, emit=None):
     t0 = time.perf_counter()
     st, hist = mg.solve(tol=0.0, max_cycles=args.steps)       # exactly K x (one V-cycle + residual norm)
     barrier()
-    secs = time.perf_counter() - t0
-    t = torch.tensor([secs], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    secs = float(t.item())
-    ranks_seen = torch.ones(1, dtype=torch.int64)
-    dist.all_reduce(ranks_seen)
+    secs = store.allreduce_max(time.perf_counter() - t0)
+    ranks_seen = store.allreduce_sum_int(1)
     prof = mg.profile()
     exchanges = mg.exchanges() - ex0
     assert st.cycles == args.steps
     if rank == 0:
-        if int(ranks_seen.item()) != args.gpus:
-            raise SystemExit(f"--gpus {args.gpus} but the collective saw {int(ranks_seen.item())} ranks")
+        if ranks_seen != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the collective saw {ranks_seen} ranks")
         es = 4 if args.dtype == "f32" else 8
         # rank 0's finest-level smoother passes: each launch must move its slab rows once
         # (read v, read b, write v'), halo rows recomputed by the deep-halo scheme included
@@ -175,11 +167,14 @@ def run(args, emit=None):
                             f"level, {wire}, transfers folded into the smoother passes), levels <= {cut} replicated, exact "
                             f"bottom solve at {(1 << cfg['coarsest_level']) - 1}^2",
                 "finest_level": L, "coarsest_level": cfg["coarsest_level"], "cut_level": cut, "mu1": args.mu1,
-                "mu2": args.mu2, "smoother": args.smoother, "step": "one V-cycle + residual norm (mgx_solve loop body)",
+                "mu2": args.mu2, "smoother": args.smoother, "arith": getattr(args, "arith", "fma"),
+                "step": "one V-cycle + residual norm (mgx_solve loop body)",
                 "parallelism": f"slab{world}", "driver": "C++ (mgx_create_rank), one process per GPU",
                 "rehearsal_all_ranks_on_one_device": rehearsal,
             },
-            "ranks_seen_by_collective": int(ranks_seen.item()),
+            "ranks_seen_by_collective": ranks_seen,
+            "transport": backend,
+            "runtime_libs": B.runtime_libs(),
             "vcycles_to_1e-8": st0.cycles if st0.converged else None,
             "single_gpu_same_workload": ref,
             "speedup_vs_single_gpu_same_workload": (st.fine_updates / secs / ref["value"]) if ref else None,
@@ -196,10 +191,7 @@ def run(args, emit=None):
                        "bytes = 3*sizeof(T) x (slab rows incl. halos) x n per pass, charged once per pass",
             },
         }
-        if emit is not None:
-            emit(out)
-        else:
-            print(json.dumps(out), flush=True)
+        out_line(out)
+    store.barrier()
     mg.close()
-    dist.barrier()
-    dist.destroy_process_group()
+    store.close()

@@ -44,6 +44,13 @@ struct orc_solver {
     double* dst_s;       /* n, 4 sin^2(pi (i+1) / (2 (n+1))) */
     double* dst_w1;      /* n x n work */
     double* dst_w2;
+    /* general per-level operators (ORC_OP_STENCIL5; mg_oracle_var.inc): A = (c, n, s, w, e) and its
+     * Jacobi splitting (D_inv, R_n, R_s, R_w, R_e) per level and precision; dense inverse of the coarsest */
+    void* var_a_f64[ORC_MAX_LEVELS][5];
+    void* var_j_f64[ORC_MAX_LEVELS][5];
+    void* var_a_f32[ORC_MAX_LEVELS][5];
+    void* var_j_f32[ORC_MAX_LEVELS][5];
+    double* var_inv;
 };
 
 static inline int orc_n(int level) { return (1 << level) - 1; } /* PS:662-664 */
@@ -62,6 +69,7 @@ void orc_config_default(orc_config* c)
     c->restrict_mode = ORC_RESTRICT_CONSISTENT;
     c->bottom = ORC_BOTTOM_EXACT;
     c->arith = ORC_ARITH_SEPARATE;
+    c->op = ORC_OP_POISSON;
 }
 
 /* ---- exact bottom solver: banded Cholesky (stands in for Eigen SparseLU,
@@ -180,11 +188,24 @@ static void orc_dst_solve(orc_solver* s, double* x)
 }
 
 /* ---- type-generic operators and schedules ------------------------------ */
+static void orc_smooth_var_f64(orc_solver* s, int level, double* v, const double* f, int mu);
+static void orc_smooth_var_f32(orc_solver* s, int level, float* v, const float* f, int mu);
+static void orc_residual_var_f64(orc_solver* s, int level, double* r, const double* v, const double* f);
+static void orc_residual_var_f32(orc_solver* s, int level, float* r, const float* v, const float* f);
+static void orc_bottom_var_f64(orc_solver* s, double* x, const double* rhs);
+static void orc_bottom_var_f32(orc_solver* s, float* x, const float* rhs);
+void orc_restrict_inject_f64(double* coarse, const double* fine, int nf, double weight);
+void orc_restrict_inject_f32(float* coarse, const float* fine, int nf, double weight);
+
 #define REAL double
 #define SUF(x) x##_f64
 #define ORC_FMA(a, b, c) fma((a), (b), (c))
 #define ORC_FMA_HW(a, b, c) __builtin_fma((a), (b), (c))
 #include "mg_oracle_impl.inc"
+#include "mg_oracle_var.inc"
+static void orc_smooth_var_f64(orc_solver* s, int level, double* v, const double* f, int mu) { var_smooth_f64(s, level, v, f, mu); }
+static void orc_residual_var_f64(orc_solver* s, int level, double* r, const double* v, const double* f) { var_residual_f64(s, level, r, v, f); }
+static void orc_bottom_var_f64(orc_solver* s, double* x, const double* rhs) { var_bottom_f64(s, x, rhs); }
 #undef ORC_FMA
 #undef ORC_FMA_HW
 #undef REAL
@@ -195,6 +216,10 @@ static void orc_dst_solve(orc_solver* s, double* x)
 #define ORC_FMA(a, b, c) fmaf((a), (b), (c))
 #define ORC_FMA_HW(a, b, c) __builtin_fmaf((a), (b), (c))
 #include "mg_oracle_impl.inc"
+#include "mg_oracle_var.inc"
+static void orc_smooth_var_f32(orc_solver* s, int level, float* v, const float* f, int mu) { var_smooth_f32(s, level, v, f, mu); }
+static void orc_residual_var_f32(orc_solver* s, int level, float* r, const float* v, const float* f) { var_residual_f32(s, level, r, v, f); }
+static void orc_bottom_var_f32(orc_solver* s, float* x, const float* rhs) { var_bottom_f32(s, x, rhs); }
 #undef ORC_FMA
 #undef ORC_FMA_HW
 #undef REAL
@@ -256,6 +281,9 @@ void orc_destroy(orc_solver* s)
     free(s->chol);
     free(s->bottom_work);
     free(s->dst_S); free(s->dst_s); free(s->dst_w1); free(s->dst_w2);
+    for (int l = 0; l < ORC_MAX_LEVELS; ++l)
+        for (int q = 0; q < 5; ++q) { free(s->var_a_f64[l][q]); free(s->var_j_f64[l][q]); free(s->var_a_f32[l][q]); free(s->var_j_f32[l][q]); }
+    free(s->var_inv);
     free(s);
 }
 
@@ -282,15 +310,19 @@ int orc_solve(orc_solver* s, const double* b, double* u, double tol, int max_cyc
     const int fmg = (s->cfg.schedule == ORC_SCHEDULE_FMG);
     int k = 0;
 
+    const int var = (s->cfg.op == ORC_OP_STENCIL5);
+    if (var && s->cfg.dtype == ORC_DTYPE_MIXED) return -1;     /* general operators: f64 or f32 hierarchies */
+#define ORC_RES64(r, u, b) do { if (var) orc_residual_var_f64(s, L, (r), (u), (b)); else orc_residual_f64((r), (u), (b), n); } while (0)
+#define ORC_RES32(r, u, b) do { if (var) orc_residual_var_f32(s, L, (r), (u), (b)); else orc_residual_f32((r), (u), (b), n); } while (0)
     if (s->cfg.dtype == ORC_DTYPE_F64) {
         double* r = (double*)s->res_f64[L];
-        orc_residual_f64(r, u, b, n);
+        ORC_RES64(r, u, b);
         hist[0] = orc_norm2_f64(r, N);
         for (k = 0; k < max_cycles; ++k) {
             if (hist[k] <= tol * hist[0]) break;
             if (k == 0 && fmg) orc_fmg_f64(s, L, u, b);
             else orc_vcycle_f64(s, L, u, b);
-            orc_residual_f64(r, u, b, n);
+            ORC_RES64(r, u, b);
             hist[k + 1] = orc_norm2_f64(r, N);
         }
         return k;
@@ -301,13 +333,13 @@ int orc_solve(orc_solver* s, const double* b, double* u, double tol, int max_cyc
         float* u32 = (float*)s->sol_f32[L];
         float* r = (float*)s->res_f32[L];
         for (size_t i = 0; i < N; ++i) { b32[i] = (float)b[i]; u32[i] = (float)u[i]; }
-        orc_residual_f32(r, u32, b32, n);
+        ORC_RES32(r, u32, b32);
         hist[0] = orc_norm2_f32(r, N);
         for (k = 0; k < max_cycles; ++k) {
             if (hist[k] <= tol * hist[0]) break;
             if (k == 0 && fmg) orc_fmg_f32(s, L, u32, b32);
             else orc_vcycle_f32(s, L, u32, b32);
-            orc_residual_f32(r, u32, b32, n);
+            ORC_RES32(r, u32, b32);
             hist[k + 1] = orc_norm2_f32(r, N);
         }
         for (size_t i = 0; i < N; ++i) u[i] = (double)u32[i];

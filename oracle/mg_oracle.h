@@ -45,7 +45,11 @@ extern "C" {
 enum { ORC_SMOOTHER_JACOBI = 0, ORC_SMOOTHER_RBGS = 1 };
 enum { ORC_DTYPE_F32 = 0, ORC_DTYPE_F64 = 1, ORC_DTYPE_MIXED = 2 };
 enum { ORC_SCHEDULE_V = 0, ORC_SCHEDULE_FMG = 1 };
-enum { ORC_RESTRICT_CONSISTENT = 0, ORC_RESTRICT_FW16 = 1 };
+enum { ORC_RESTRICT_CONSISTENT = 0, ORC_RESTRICT_FW16 = 1,
+       ORC_RESTRICT_INJECT = 2 /* MF:122-130 as written */, ORC_RESTRICT_INJECT4 = 3 /* 4 x injection: h^2-consistent */ };
+/* operator of the hierarchy: the constant 5-point Poisson stencil (PS), or per-level five-coefficient
+ * operators with MF's Jacobi  v <- R_omega v + omega D^-1 b  and a dense direct bottom solve (MF:16-41, 63-96) */
+enum { ORC_OP_POISSON = 0, ORC_OP_STENCIL5 = 1 };
 enum { ORC_BOTTOM_EXACT = 0, ORC_BOTTOM_SMOOTH = 1,
        ORC_BOTTOM_DST = 2 /* exact too: sine transform, in the device's operation order (mg_oracle.c) */ };
 /* how the Jacobi update of PS:138-142 is rounded: the reference's five library calls as five roundings
@@ -68,6 +72,7 @@ typedef struct {
     int restrict_mode;   /* ORC_RESTRICT_* (D4) */
     int bottom;          /* ORC_BOTTOM_* (D8) */
     int arith;           /* ORC_ARITH_* */
+    int op;              /* ORC_OP_* */
 } orc_config;
 
 void orc_config_default(orc_config* c);
@@ -97,10 +102,42 @@ void orc_prolong_add_f32(float* v, const float* coarse, int nc);
 double orc_norm2_f64(const double* x, size_t len);
 double orc_norm2_f32(const float* x, size_t len);
 
+/* ---- general per-level operators (MF's draft; mg_oracle_var.inc) ------ */
+/* A_jacobi_sp_dict from A_sp_dict (MF:28-32): D_inv and the off-diagonals of R_omega = I - omega D^-1 A */
+void orc_var_build_jacobi_f64(const double* c, const double* an, const double* as, const double* aw, const double* ae, int n,
+                              double omega, double* dinv, double* rn, double* rs, double* rw, double* re);
+void orc_var_build_jacobi_f32(const float* c, const float* an, const float* as, const float* aw, const float* ae, int n,
+                              double omega, float* dinv, float* rn, float* rs, float* rw, float* re);
+/* MF:75-96: mu sweeps of v <- R_omega v + omega D^-1 b */
+void orc_var_jacobi_f64(double* v, const double* b, int n, int mu, double omega, const double* dinv, const double* rn,
+                        const double* rs, const double* rw, const double* re);
+void orc_var_jacobi_f32(float* v, const float* b, int n, int mu, double omega, const float* dinv, const float* rn,
+                        const float* rs, const float* rw, const float* re);
+/* MF:150-153: r = b - A v */
+void orc_var_residual_f64(double* r, const double* v, const double* b, int n, const double* c, const double* an,
+                          const double* as, const double* aw, const double* ae);
+void orc_var_residual_f32(float* r, const float* v, const float* b, int n, const float* c, const float* an,
+                          const float* as, const float* aw, const float* ae);
+/* MF:122-130 injection, times `weight` */
+void orc_restrict_inject_f64(double* coarse, const double* fine, int nf, double weight);
+void orc_restrict_inject_f32(float* coarse, const float* fine, int nf, double weight);
+/* the reference's own data layout: CSR (MF:33-41).  y = alpha (A x); MF:75-96 on CSR R_omega + diagonal D_inv */
+void orc_csr_gemv_f64(const int32_t* indptr, const int32_t* indices, const double* values, const double* x, double* y, int N, double alpha);
+void orc_csr_gemv_f32(const int32_t* indptr, const int32_t* indices, const float* values, const float* x, float* y, int N, double alpha);
+void orc_csr_jacobi_f64(double* v, const double* b, int N, int mu, double omega, const int32_t* r_indptr,
+                        const int32_t* r_indices, const double* r_values, const double* dinv);
+void orc_csr_jacobi_f32(float* v, const float* b, int N, int mu, double omega, const int32_t* r_indptr,
+                        const int32_t* r_indices, const float* r_values, const float* dinv);
+
 /* ---- solver ---------------------------------------------------------- */
 typedef struct orc_solver orc_solver;
 orc_solver* orc_create(const orc_config* cfg);
 void orc_destroy(orc_solver* s);
+
+/* ORC_OP_STENCIL5: the operator of `level` (ProblemVar::A_sp_dict[level], MF:19) as five interior n x n
+ * coefficient arrays; every level of the hierarchy must be set before a schedule runs. */
+void orc_var_set_stencil_f64(orc_solver* s, int level, const double* c, const double* an, const double* as, const double* aw, const double* ae);
+void orc_var_set_stencil_f32(orc_solver* s, int level, const double* c, const double* an, const double* as, const double* aw, const double* ae);
 
 /* exact bottom solve A x = rhs on the coarsest level (MF:63-72, MF:137-139):
  * banded Cholesky in double. */

@@ -18,7 +18,8 @@ _LIB_PATH = os.path.join(_HERE, "build", "libmg_oracle.so")
 SMOOTHER_JACOBI, SMOOTHER_RBGS = 0, 1
 DTYPE_F32, DTYPE_F64, DTYPE_MIXED = 0, 1, 2
 SCHEDULE_V, SCHEDULE_FMG = 0, 1
-RESTRICT_CONSISTENT, RESTRICT_FW16 = 0, 1
+RESTRICT_CONSISTENT, RESTRICT_FW16, RESTRICT_INJECT, RESTRICT_INJECT4 = 0, 1, 2, 3
+OP_POISSON, OP_STENCIL5 = 0, 1
 BOTTOM_EXACT, BOTTOM_SMOOTH, BOTTOM_DST = 0, 1, 2
 ARITH_SEPARATE, ARITH_FMA = 0, 1
 
@@ -29,7 +30,7 @@ class Config(C.Structure):
         ("mu0", C.c_int), ("mu1", C.c_int), ("mu2", C.c_int),
         ("omega", C.c_double),
         ("smoother", C.c_int), ("dtype", C.c_int), ("schedule", C.c_int),
-        ("restrict_mode", C.c_int), ("bottom", C.c_int), ("arith", C.c_int),
+        ("restrict_mode", C.c_int), ("bottom", C.c_int), ("arith", C.c_int), ("op", C.c_int),
     ]
 
 
@@ -60,6 +61,14 @@ def lib() -> C.CDLL:
             getattr(L, f"orc_restrict_{suf}").argtypes = [p, p, C.c_int, C.c_int]
             getattr(L, f"orc_prolong_{suf}").argtypes = [p, p, C.c_int]
             getattr(L, f"orc_prolong_add_{suf}").argtypes = [p, p, C.c_int]
+            getattr(L, f"orc_var_build_jacobi_{suf}").argtypes = [p] * 5 + [C.c_int, C.c_double] + [p] * 5
+            getattr(L, f"orc_var_jacobi_{suf}").argtypes = [p, p, C.c_int, C.c_int, C.c_double] + [p] * 5
+            getattr(L, f"orc_var_residual_{suf}").argtypes = [p, p, p, C.c_int] + [p] * 5
+            getattr(L, f"orc_restrict_inject_{suf}").argtypes = [p, p, C.c_int, C.c_double]
+            i32 = C.POINTER(C.c_int32)
+            getattr(L, f"orc_csr_gemv_{suf}").argtypes = [i32, i32, p, p, p, C.c_int, C.c_double]
+            getattr(L, f"orc_csr_jacobi_{suf}").argtypes = [p, p, C.c_int, C.c_int, C.c_double, i32, i32, p, p]
+            getattr(L, f"orc_var_set_stencil_{suf}").argtypes = [vp, C.c_int] + [dp] * 5
             getattr(L, f"orc_norm2_{suf}").argtypes = [p, C.c_size_t]
             getattr(L, f"orc_norm2_{suf}").restype = C.c_double
             getattr(L, f"orc_bottom_solve_{suf}").argtypes = [vp, p, p]
@@ -150,6 +159,89 @@ def prolong_add(v, coarse):
     return v
 
 
+# -- general per-level operators (MF's draft): five-coefficient stencils and CSR ----------------
+def var_build_jacobi(c, an, as_, aw, ae, omega=2.0 / 3.0):
+    """A_jacobi_sp_dict from A_sp_dict (MF:28-32): (dinv, rn, rs, rw, re)"""
+    a = [np.ascontiguousarray(x, dtype=c.dtype) for x in (c, an, as_, aw, ae)]
+    out = [np.empty_like(a[0]) for _ in range(5)]
+    getattr(lib(), f"orc_var_build_jacobi_{_suf(a[0])}")(*[_ptr(x) for x in a], a[0].shape[0], omega, *[_ptr(x) for x in out])
+    return out
+
+
+def var_jacobi(v, b, mu, omega, jac):
+    """MF:75-96: mu sweeps of v <- R_omega v + omega D^-1 b; jac = var_build_jacobi(...)"""
+    v = np.array(v, copy=True, order="C")
+    b = np.ascontiguousarray(b, dtype=v.dtype)
+    j = [np.ascontiguousarray(x, dtype=v.dtype) for x in jac]
+    getattr(lib(), f"orc_var_jacobi_{_suf(v)}")(_ptr(v), _ptr(b), v.shape[0], mu, omega, *[_ptr(x) for x in j])
+    return v
+
+
+def var_residual(v, b, coef):
+    """MF:150-153: b - A v, coef = (c, n, s, w, e)"""
+    v = np.ascontiguousarray(v)
+    b = np.ascontiguousarray(b, dtype=v.dtype)
+    a = [np.ascontiguousarray(x, dtype=v.dtype) for x in coef]
+    r = np.empty_like(v)
+    getattr(lib(), f"orc_var_residual_{_suf(v)}")(_ptr(r), _ptr(v), _ptr(b), v.shape[0], *[_ptr(x) for x in a])
+    return r
+
+
+def restrict_inject(fine, weight=1.0):
+    """MF:122-130"""
+    fine = np.ascontiguousarray(fine)
+    nc = (fine.shape[0] - 1) // 2
+    c = np.empty((nc, nc), dtype=fine.dtype)
+    getattr(lib(), f"orc_restrict_inject_{_suf(fine)}")(_ptr(c), _ptr(fine), fine.shape[0], weight)
+    return c
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def csr_gemv(indptr, indices, values, x, alpha=1.0):
+    """y = alpha (A x) on the reference's data layout (MF:33-41; oneMKL sparse::gemv, beta = 0)"""
+    x = np.ascontiguousarray(x)
+    values = np.ascontiguousarray(values, dtype=x.dtype)
+    ip, ipp = _i32(indptr)
+    ix, ixp = _i32(indices)
+    y = np.empty_like(x)
+    getattr(lib(), f"orc_csr_gemv_{_suf(x)}")(ipp, ixp, _ptr(values), _ptr(x), _ptr(y), len(ip) - 1, alpha)
+    return y
+
+
+def csr_jacobi(v, b, mu, omega, r_indptr, r_indices, r_values, dinv):
+    """MF:75-96 on a CSR R_omega and the diagonal of D_inv"""
+    v = np.array(v, copy=True, order="C")
+    b = np.ascontiguousarray(b, dtype=v.dtype)
+    r_values = np.ascontiguousarray(r_values, dtype=v.dtype)
+    dinv = np.ascontiguousarray(dinv, dtype=v.dtype)
+    ip, ipp = _i32(r_indptr)
+    ix, ixp = _i32(r_indices)
+    getattr(lib(), f"orc_csr_jacobi_{_suf(v)}")(_ptr(v), _ptr(b), v.size, mu, omega, ipp, ixp, _ptr(r_values), _ptr(dinv))
+    return v
+
+
+def stencil_from_nodes(a_nodes, level, finest):
+    """five-point discretisation of -div(a grad u) on `level` from the nodal coefficient of the finest grid
+    ((2^finest + 1)^2 values, boundary nodes included), sampled at the level's nodes; face coefficient = mean of
+    its two nodes.  Returns interior n x n arrays (c, n, s, w, e) in double - the statement the device's
+    mgx_set_coefficient follows operation by operation."""
+    q = 1 << (finest - level)
+    a = np.ascontiguousarray(a_nodes, dtype=np.float64)[::q, ::q]
+    N = 1 << level
+    assert a.shape == (N + 1, N + 1)
+    ctr = a[1:N, 1:N]
+    fn = 0.5 * (ctr + a[0:N - 1, 1:N])
+    fs = 0.5 * (ctr + a[2:N + 1, 1:N])
+    fw = 0.5 * (ctr + a[1:N, 0:N - 1])
+    fe = 0.5 * (ctr + a[1:N, 2:N + 1])
+    c = ((fn + fw) + fe) + fs
+    return c, -fn, -fs, -fw, -fe
+
+
 def norm2(x):
     x = np.ascontiguousarray(x)
     return getattr(lib(), f"orc_norm2_{_suf(x)}")(_ptr(x), x.size)
@@ -200,6 +292,17 @@ class Solver:
         x = np.empty_like(rhs)
         getattr(lib(), f"orc_bottom_solve_{_suf(rhs)}")(self._h, _ptr(x), _ptr(rhs))
         return x
+
+    def set_stencil(self, level, c, an, as_, aw, ae):
+        """ProblemVar::A_sp_dict[level] (MF:19): the level's operator as five interior coefficient arrays"""
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (c, an, as_, aw, ae)]
+        suf = "f64" if self.cfg.dtype == DTYPE_F64 else "f32"
+        getattr(lib(), f"orc_var_set_stencil_{suf}")(self._h, level, *[_ptr(x) for x in a])
+
+    def set_coefficient(self, a_nodes):
+        """every level's operator from the nodal coefficient of the finest grid (stencil_from_nodes)"""
+        for lvl in range(self.cfg.coarsest_level, self.cfg.finest_level + 1):
+            self.set_stencil(lvl, *stencil_from_nodes(a_nodes, lvl, self.cfg.finest_level))
 
     def vcycle(self, level, v, f):
         v = np.array(v, copy=True, order="C")

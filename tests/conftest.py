@@ -3,12 +3,11 @@ import sys
 
 import pytest
 
-try:
-    # before libmgx.so is ever loaded: the torch wheel and libmgx bring a HIP runtime each, the one
-    # loaded first serves both, and torch's device layer only comes up on its own
-    import torch  # noqa: F401
-except Exception:  # pragma: no cover - torch is optional for the single-GPU tests
-    torch = None
+# No torch here: the torch wheel bundles its own libamdhip64 / libhsa-runtime64 / librccl with the SONAMEs of
+# the /opt/rocm ones libmgx is built against, and whichever copy is loaded first serves the whole process.
+# The GPU tests must exercise the library on ITS stack, so nothing imports torch before libmgx.so is loaded
+# (device buffers: tests/hipmem.py; rank processes: the TCP store of rendezvous.py).  The CPU-only plan tests
+# (tests/test_dist_plan_cpu.py) do use torch.distributed / gloo: no GPU is touched there.
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -39,9 +38,11 @@ def po():
 
 
 def have_gpu() -> bool:
+    """is there a HIP device?  Asked of the runtime libmgx links against (tests/hipmem.py)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     try:
-        import torch
+        import hipmem
 
-        return torch.cuda.is_available()
+        return hipmem.device_count() > 0
     except Exception:
         return False

