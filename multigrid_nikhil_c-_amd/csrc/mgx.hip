@@ -365,17 +365,17 @@ inline int fold_kcap(const FuseCfg& f, int smoother, int N, int post, bool f64)
     int k = N >= 8192 ? f.fold_kmax_big : f.fold_kmax;
     if (post == 0) k = std::min(k, f.fold_kmax_nopost);
     if (smoother == MGX_SMOOTHER_RBGS) k = std::min(k, env_int("MGX_FOLD_KMAX_GS", 10));
-    return f64 ? k : std::min(k, 8);           // no 10-level folded kernels in float
+    return k;
 }
 
-inline double fold_pass_cost(int K, int smoother, int N, int post, bool f64)
+inline double fold_pass_cost(int K, int smoother, int N, int post, bool f64, int arith)
 {
     const bool rbgs = (smoother == MGX_SMOOTHER_RBGS);
-    if (!cycle_k_supported(K, rbgs, f64, post)) return -1.0;
+    if (!cycle_k_supported(K, rbgs, f64, post, false, arith)) return -1.0;
     (void)N;
     if (rbgs) return K <= 4 ? 1.0 : (K == 6 ? 1.1 : (K == 8 ? 1.3 : 2.4));
     if (K <= 5) return 1.0;
-    if (!f64) return K == 6 ? 1.34 : 1.53;
+    if (!f64) return K == 6 ? 1.34 : (K == 8 ? 1.53 : 1.75);      // (10 levels: rhs window in LDS since round 3)
     if (K == 6) return 1.05;
     if (K == 8) return 1.12;
     return 1.46;
@@ -383,7 +383,7 @@ inline double fold_pass_cost(int K, int smoother, int N, int post, bool f64)
 
 // parts[] = sweeps per pass, deepest first (the last pass carries the residual stage, which is
 // what gets expensive with depth; a leading single sweep could not synthesise a zero input)
-inline int plan_folded(const FuseCfg& f, int smoother, int N, int mu, int post, bool f64, int* parts)
+inline int plan_folded(const FuseCfg& f, int smoother, int N, int mu, int post, bool f64, int* parts, bool pre = false)
 {
     const int per = (smoother == MGX_SMOOTHER_RBGS) ? 2 : 1;
     const int smax = std::max(1, fold_kcap(f, smoother, N, post, f64) / per);
@@ -392,8 +392,10 @@ inline int plan_folded(const FuseCfg& f, int smoother, int N, int mu, int post, 
     best[0] = 0.0;
     for (int m = 1; m <= mu; ++m)
         for (int k = 1; k <= std::min(m, smax); ++k) {
-            const double c = fold_pass_cost(per * k, smoother, N, post, f64);
+            const double c = fold_pass_cost(per * k, smoother, N, post, f64, f.arith);
             if (c < 0.0) continue;
+            // a block done in ONE pass carries the correction AND the residual stage: some depths exist for either only
+            if (k == mu && m == mu && !cycle_k_supported(per * k, smoother == MGX_SMOOTHER_RBGS, f64, post, pre, f.arith)) continue;
             const double t = best[m - k] + c + 1e-3;      // equal sums: fewer passes
             if (t < best[m] - 1e-12) { best[m] = t; pick[m] = k; }
         }
@@ -423,14 +425,14 @@ int fold_plan(const mgx_solver* s, const Level& l, int mu, bool pre, int post, i
             const int K = per * forced[i];
             const bool folded = (i == 0 && pre) || (i == nf - 1 && post != 0);
             const int q = (i == nf - 1) ? post : 0;
-            ok = ok && K <= 10 && (folded ? cycle_k_supported(K, rbgs, l.f64, q, pre && i == 0) : (K != 7 && K != 9 && (!rbgs || K % 2 == 0)));
+            ok = ok && K <= 10 && (folded ? cycle_k_supported(K, rbgs, l.f64, q, pre && i == 0, f.arith) : (K != 7 && K != 9 && (!rbgs || K % 2 == 0)));
         }
         if (ok && sum == mu) {
             for (int i = 0; i < nf; ++i) parts[i] = forced[i];
             return nf;
         }
     }
-    return plan_folded(f, s->cfg.smoother, l.N, mu, post, l.f64, parts);
+    return plan_folded(f, s->cfg.smoother, l.N, mu, post, l.f64, parts, pre);
 }
 
 // mu Jacobi sweeps on a whole level with the prolongation+correction applied while
@@ -507,7 +509,7 @@ bool fold_eligible(const mgx_solver* s, const Level& l, int mu, bool pre = false
     int parts[64];
     const int np = fold_plan(s, l, mu, pre, post, parts);
     for (int p = 0; p < np; ++p)
-        if (!cycle_k_supported(per * parts[p], rbgs, l.f64, p == np - 1 ? post : 0, pre && p == 0)) return false;
+        if (!cycle_k_supported(per * parts[p], rbgs, l.f64, p == np - 1 ? post : 0, pre && p == 0, s->fuse.arith)) return false;
     // the norm partials of the folded pass must fit the reduction buffer
     return true;
 }
@@ -1745,7 +1747,7 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
         fc.fold_kmax = std::min(fc.fold_kmax, 8); fc.fold_kmax_big = std::min(fc.fold_kmax_big, 8);
     }
     int parts[64];
-    const int np = plan_folded(fc, rbgs ? MGX_SMOOTHER_RBGS : MGX_SMOOTHER_JACOBI, N, mu, post, sizeof(T) == 8, parts);
+    const int np = plan_folded(fc, rbgs ? MGX_SMOOTHER_RBGS : MGX_SMOOTHER_JACOBI, N, mu, post, sizeof(T) == 8, parts, coarse_e != nullptr);
     const T om = (T)omega;
     const T c0 = (T)(1.0 - (double)om);
     const T c1 = (T)((double)om / 4.0);
@@ -1783,7 +1785,7 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
         if (hi > lo) {
             const int R = fuse_rows(fc, N, K, sizeof(T) == 8, hi - lo);
             if (P || Q) {
-                if (!cycle_k_supported(K, rbgs, sizeof(T) == 8, Q, P)) return MGX_ERR_INVALID;
+                if (!cycle_k_supported(K, rbgs, sizeof(T) == 8, Q, P, AR)) return MGX_ERR_INVALID;
                 fa.row_lo = lo + f->row0; fa.row_hi = hi + f->row0;
                 int rc;
                 const int Rc = fuse_rows_auto(fc, N, K, sizeof(T) == 8) ? -R : R;

@@ -460,10 +460,12 @@ struct DistProf {
 };
 
 // passes a folded block of mu sweeps is split into (what mgx_slab_cycle will launch)
-int dist_block_launches(const mgx_dist* d, int N, int mu, int post)
+int dist_block_launches(const mgx_dist* d, int N, int mu, int post, bool pre = false)
 {
     int parts[64];
-    return plan_folded(fuse_cfg(), d->cfg.smoother, N, mu, post, d->f64, parts);
+    FuseCfg fc = fuse_cfg();
+    fc.arith = d->cfg.arith;
+    return plan_folded(fc, d->cfg.smoother, N, mu, post, d->f64, parts, pre);
 }
 
 // the CYCLE operation of a plan on local rows [row_lo,row_hi) of its range, on `stream` (the whole
@@ -541,7 +543,7 @@ int dist_local_op(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op& o
         }
         case MGX_DOP_CYCLE: {
             DistProf pr(d, sl, timed, MGX_PROF_SMOOTH_FINE, o.mu);
-            pr.launches(dist_block_launches(d, sl.plan.L(o.level).N, o.mu, o.post));
+            pr.launches(dist_block_launches(d, sl.plan.L(o.level).N, o.mu, o.post, o.pre != 0));
             int flag = 0;
             const int rc = dist_cycle_rows(s, d, sl, o, o.row_lo, o.row_hi, sl.st, &flag);
             if (rc != MGX_OK) return rc;

@@ -1203,7 +1203,8 @@ cycle_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
 // moves); no barrier (a wave only ever touches its own ring).  LDS instructions do not occupy the
 // vector ALU, which is what these passes are bound by.  Same values, same order: same bits.
 constexpr int kBRing = 12;                     // >= K + 1 for K <= 10, multiple of the 3 rotation phases
-template <typename T, int K, int POST, int SM> constexpr bool cycle_b_in_lds() { return sizeof(T) == 8 && K >= 8; }
+// (float: from 10 levels - the 8-level float bodies fit their registers with the window in them and keep 3-step trips)
+template <typename T, int K, int POST, int SM> constexpr bool cycle_b_in_lds() { return (sizeof(T) == 8 && K >= 8) || (sizeof(T) == 4 && K >= 10); }
 template <typename T> struct LdsVec;
 template <> struct LdsVec<double> { typedef double v __attribute__((ext_vector_type(2))); };
 template <> struct LdsVec<float> { typedef float v __attribute__((ext_vector_type(4))); };
@@ -1495,8 +1496,16 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
 
 // deep passes (rhs ring in LDS): ask for two workgroups per CU = two waves per SIMD, i.e. at most 256
 // registers - without it the compiler settles for one wave per SIMD and accumulator-register spills
+// workgroups per CU the compiler must make room for (= waves per SIMD): the deep passes with their rhs window in
+// LDS ask for two (at most 256 registers).  Three (168 registers) was measured in round 3 for the 10-level
+// pre-smoothing kernels, which need 173-177: they spill 60-116 B per lane into the interior loop and the pass takes
+// 0.53 instead of 0.40 ms at 8192^2 (profiles/r03_experiments.md).
+template <typename T, int K, int PRE, int POST, int SM, int AR> constexpr int cycle_waves()
+{
+    return cycle_b_in_lds<T, K, POST, SM>() ? 2 : 1;
+}
 template <typename T, int K, int PRE, int POST, int SM = 0, int AR = 0>
-__global__ void __launch_bounds__(kBlock, (cycle_b_in_lds<T, K, POST, SM>() ? 2 : 1))
+__global__ void __launch_bounds__(kBlock, (cycle_waves<T, K, PRE, POST, SM, AR>()))
 k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
                const T* __restrict__ coarse_e,                       // PRE
                T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,   // POST == 1

@@ -432,11 +432,13 @@ int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, i
     if constexpr (sizeof(T) == 8 || PRE == 1 || POST == 0) {
         if (K == 8) return launch_cycle_k<T, 8, PRE, POST, SM, AR>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
     }
-    // 10 levels with folded stages: double only (the float variants, whose packed arithmetic
-    // needs aligned register pairs, exceed 256 VGPRs), and not the two most register-hungry
-    // combinations (correction AND restriction in one pass; red-black GS with the restriction):
-    // with the rhs window in LDS every instantiated variant fits 256 registers = two waves per SIMD
-    if constexpr (sizeof(T) == 8 && !(PRE == 1 && POST == 1) && !(SM == 1 && POST == 1)) {
+    // 10 levels with folded stages: not the most register-hungry combinations (correction AND restriction in
+    // one pass; red-black GS with the restriction; in float - packed arithmetic wants aligned register pairs -
+    // the correction with the norm): with the rhs window in LDS every instantiated variant fits 256
+    // registers = two waves per SIMD, float ones included since round 3 (cycle_b_in_lds)
+    // (and the float pre-smoothing pass with the restriction only in FMA mode: the separately rounded one spills 3 dwords)
+    if constexpr (!(PRE == 1 && POST == 1) && !(SM == 1 && POST == 1) && !(sizeof(T) == 4 && PRE == 1 && POST == 2) &&
+                  !(sizeof(T) == 4 && POST == 1 && AR == 0)) {
         if (K == 10) return launch_cycle_k<T, 10, PRE, POST, SM, AR>(vin, b, vout, fa, N, pitch, c0, c1, R, st);
     }
     if constexpr (SM == 0) {
@@ -451,9 +453,9 @@ int launch_cycle(int K, const T* vin, const T* b, T* vout, const FoldArgs& fa, i
 }
 
 // levels per pass the folded kernels are instantiated for
-inline bool cycle_k_supported(int K, bool rbgs, bool f64, int post = 0, bool pre = false)
+inline bool cycle_k_supported(int K, bool rbgs, bool f64, int post, bool pre, int arith)
 {
-    if (K == 10) return f64 && !(pre && post == 1) && !(rbgs && post == 1);
+    if (K == 10) return !(pre && post == 1) && !(rbgs && post == 1) && !(!f64 && pre && post == 2) && !(!f64 && post == 1 && arith == 0);
     if (K == 8 && !f64 && !pre && post != 0) return false;
     return rbgs ? (K == 2 || K == 4 || K == 6 || K == 8) : (K >= 1 && K <= 8 && K != 7);
 }

@@ -14,7 +14,15 @@ _hip = None
 def hip():
     global _hip
     if _hip is None:
+        # the copy of the runtime this process already has (libmgx's, if the library was loaded first), else /opt/rocm's
         path = "/opt/rocm/lib/libamdhip64.so"
+        try:
+            for line in open("/proc/self/maps"):
+                if "libamdhip64" in line and "/" in line:
+                    path = line[line.index("/"):].strip()
+                    break
+        except OSError:
+            pass
         _hip = C.CDLL(path if os.path.exists(path) else "libamdhip64.so")
         _hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         _hip.hipFree.argtypes = [C.c_void_p]
@@ -82,7 +90,8 @@ class DevArray:
         assert hip().hipMemcpy(out.data_ptr(), self.data_ptr(), self.nbytes, 3) == 0       # device to device
         return out
 
-    contiguous = clone      # a row slice is contiguous already; a copy keeps the call sites simple
+    def contiguous(self):
+        return self         # whole leading rows of a C-contiguous array are contiguous
 
     def item(self):
         assert int(np.prod(self.shape)) == 1

@@ -10,9 +10,10 @@ import sys
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
+
+# torch (gloo, CPU tensors) is imported inside the functions that use it, never at module level: `pytest tests -m gpu`
+# imports every test module while collecting, and the torch wheel's bundled ROCm runtime must not get into a
+# process that is about to run libmgx on the GPU (tests/conftest.py)
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,6 +28,9 @@ def _mgx_cfg(cfg):
 def _worker(rank, world, port, cfg, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
     import __graft_entry__ as ge
     from dist_cpu_ops import CpuSlabOps, OracleCoarseSolver
     from oracle import pyoracle as po
@@ -58,6 +62,8 @@ def _worker(rank, world, port, cfg, ret):
 
 
 def _run(world, cfg):
+    import torch.multiprocessing as mp
+
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 29500 + (os.getpid() % 2000) + world

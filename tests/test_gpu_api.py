@@ -184,3 +184,19 @@ def test_vcycle_zero_equals_zero_guess_then_vcycle(pkg, po, monkeypatch, cfg, gr
             assert np.array_equal(a.get_solution(), b.get_solution()), (cfg, it)
         if graph == "1":
             assert 1 <= a.graphs_cached() <= 2
+
+
+def test_this_process_runs_one_rocm_stack_the_one_libmgx_was_built_against(pkg):
+    """libmgx.so is built by /opt/rocm's hipcc with RUNPATH /opt/rocm/lib; the torch wheel bundles another copy of
+    libamdhip64 / libhsa-runtime64 / librccl with the same SONAMEs, and whichever is loaded first serves the whole
+    process.  The GPU tests (the records the driver keeps) must exercise the library on ITS stack: exactly one copy
+    of each runtime library mapped, from /opt/rocm, and no torch in sys.modules."""
+    import sys
+
+    with pkg.Multigrid(finest_level=6, coarsest_level=5) as mg:
+        mg.fill_rhs(1, 0.0)
+    libs = pkg.runtime_libs()
+    for name in ("libamdhip64", "libhsa-runtime64", "librccl"):
+        paths = [p for p in libs if name in p]
+        assert len(paths) == 1 and paths[0].startswith("/opt/rocm"), libs
+    assert "torch" not in sys.modules

@@ -93,6 +93,35 @@ def test_oracle_operator_application_matches_the_reference_matrix(po, ref):
     assert np.allclose(v1, v + r_ref / 4.0, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("arith", [0, 1])
+def test_oracle_jacobi_at_the_reference_weight_against_the_reference_matrix(po, ref, arith):
+    """A1: one sweep of PS:125-147 in fp32 at omega = 2/3 (PS:127) on integer data == (1 - w) v + (w/4) f +
+    (-w/4)(LU_ref v) (PS:138-142), LU_ref from the reference's own `lu` triplets (sign D1): <= 2 ulp"""
+    nodes, n = 17, 15
+    LU = np.zeros((n * n, n * n))
+    np.add.at(LU, (ref[f"coo{nodes}_rows_lu"], ref[f"coo{nodes}_cols_lu"]), ref[f"coo{nodes}_vals_lu"].astype(np.float64))
+    LU = -LU
+    rng = np.random.default_rng(17)
+    v = rng.integers(-8, 9, (n, n)).astype(np.float64)
+    f = rng.integers(-8, 9, (n, n)).astype(np.float64)
+    for cast in (np.float32, np.float64):
+        om = float(cast(2.0 / 3.0))
+        want = (1.0 - om) * v + (om / 4.0) * f + (-om / 4.0) * (LU @ v.ravel()).reshape(n, n)
+        got = po.jacobi(v.astype(cast), f.astype(cast), 1, 2.0 / 3.0, arith=arith)
+        assert np.max(np.abs(got.astype(np.float64) - want)) <= 2 * np.finfo(cast).eps * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("nc", [7, 31, 63])
+def test_oracle_restriction_is_the_transpose_of_the_reference_interpolation(po, ref, nc):
+    """A3: <R r, e> = <r, P_ref e> with P_ref e computed by the reference (interp_out_*)"""
+    e = ref[f"interp_in_{nc}"].astype(np.float64)
+    pe = ref[f"interp_out_{nc}"].astype(np.float64)
+    r = np.random.default_rng(nc).integers(-16, 17, pe.shape).astype(np.float64)
+    Rr = po.restrict(r)
+    # (the reference interpolates in fp32: its values carry float rounding)
+    assert abs(float(np.sum(Rr * e)) - float(np.sum(r * pe))) <= 2 * np.finfo(np.float32).eps * np.sum(np.abs(r * pe))
+
+
 def test_as_written_defects_d2_and_d3_are_what_the_survey_says(ref):
     # D3: `(1 / 16)` at PS:539 is integer 0 -> restriction2d returns zeros whatever the input
     assert np.any(ref["restrict_in_7"] != 0) and np.all(ref["restrict_out_7"] == 0)

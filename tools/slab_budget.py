@@ -9,7 +9,9 @@ import __graft_entry__ as ge
 
 pkg = ge.load_package()
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 14
-kw = dict(finest_level=L, coarsest_level=7, mu0=0, mu1=10, mu2=10, schedule=pkg.SCHEDULE_V)
+arith = sys.argv[2] if len(sys.argv) > 2 else "fma"          # what bench.py runs
+kw = dict(finest_level=L, coarsest_level=7, mu0=0, mu1=10, mu2=10, schedule=pkg.SCHEDULE_V,
+          arith=pkg.ARITH_FMA if arith == "fma" else pkg.ARITH_SEPARATE)
 res = {}
 for P in (1, 2, 4, 8):
     extra = {} if P == 1 else dict(n_gpus=P, devices=[0] * P)
@@ -26,5 +28,5 @@ for P in (1, 2, 4, 8):
             best = min(best, (time.perf_counter() - t0) / 5 * 1e3)
         ex = mg.exchanges() if P > 1 else 0
     res[P] = best
-    print(f"L{L} P={P}: {best:.3f} ms per cycle for all slabs, {best / P:.3f} ms per GPU-equivalent"
+    print(f"L{L} {arith} P={P}: {best:.3f} ms per cycle for all slabs, {best / P:.3f} ms per GPU-equivalent"
           f" (x{res[1] / (best / P):.2f} of one GPU's {res[1]:.3f} ms)", flush=True)
