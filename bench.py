@@ -170,9 +170,19 @@ def run_single(args):
     mg.fill_rhs(1, 0.0)               # b = h^2 8 pi^2 sin(2 pi x) sin(2 pi y)
     mg.fill_guess_random(12345)       # u0 ~ U(-1,1)
     # ---- the "V-cycles to 1e-8" half of the metric (untimed here) ----
+    mg.solve(tol=0.0, max_cycles=1)   # (graph capture, code objects, clocks: not part of a solve's own time)
+    mg.fill_guess_random(12345)
     st0, hist0 = mg.solve(tol=1e-8, max_cycles=60)
     cycles_to_tol = st0.cycles if st0.converged else None
     solve_seconds = st0.seconds
+    # the same cycles on an iterate that is still far from converged: the first five from a fresh random guess
+    # (the K timed steps below mostly run on an iterate already at the rounding floor; same kernels, same bytes)
+    mg.fill_guess_random(54321)
+    mg.synchronize()
+    t0 = time.perf_counter()
+    st5, _ = mg.solve(tol=0.0, max_cycles=5)
+    mg.synchronize()
+    first5_ms = (time.perf_counter() - t0) / 5 * 1e3
     # ---- warmup + timed steps on a fresh random guess ----
     mg.fill_guess_random(12345)
     if args.warmup > 0:
@@ -217,7 +227,7 @@ def run_single(args):
                   f"the cycle's correction, residual+restriction and norm ride in the same passes)")
     else:
         kernel = f"k_jacobi_rows<{tname}>"
-    wl_key = f"L{L}_{args.smoother}_{args.dtype}_mu{args.mu1}"
+    wl_key = f"L{L}_{args.smoother}_{args.dtype}_mu{args.mu1}" + ("_fma" if args.arith == "fma" and args.smoother == "jacobi" else "")
     traffic = pmc_traffic(wl_key)
     out = {
         "metric": "fine_grid_stencil_updates_per_sec",
@@ -235,14 +245,17 @@ def run_single(args):
         "config": {
             "workload": f"2D Poisson {1 << L}^2 (n={n} interior), {L - cfg['coarsest_level'] + 1}-level V({args.mu1},{args.mu2}) cycle, "
                         f"{'weighted Jacobi w=%.4f' % args.omega if args.smoother == 'jacobi' else 'red-black Gauss-Seidel'}, "
-                        f"{args.dtype}, exact bottom solve at {(1 << cfg['coarsest_level']) - 1}^2, "
+                        f"{args.dtype}, Jacobi update {'contracted (fma)' if args.arith == 'fma' else 'separately rounded'}, "
+                        f"exact bottom solve at {(1 << cfg['coarsest_level']) - 1}^2, "
                         f"rhs h^2*8pi^2 sin(2pi x)sin(2pi y), u0~U(-1,1)",
             "finest_level": L, "coarsest_level": cfg["coarsest_level"], "mu1": args.mu1, "mu2": args.mu2,
-            "smoother": args.smoother, "step": "one V-cycle + residual norm (mgx_solve loop body)",
+            "smoother": args.smoother, "arith": args.arith, "step": "one V-cycle + residual norm (mgx_solve loop body)",
             "parallelism": "1 GPU",
         },
         "vcycles_to_1e-8": cycles_to_tol,
         "seconds_to_1e-8": solve_seconds,
+        "ms_per_step_first_5_cycles_from_a_random_guess": first5_ms,      # incl. the initial residual norm (one more pass)
+        "runtime_libs": pkg.runtime_libs(),
         "residual_history_to_1e-8": [float(x) for x in hist0],
         "roofline": {
             "bound": "hbm",

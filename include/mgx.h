@@ -304,11 +304,14 @@ MGX_API int mgx_slab_rbgs(const mgx_slab* s, void* u, const void* b, void* tmp,
  *                      (scratch as for mgx_slab_residual_sumsq).
  * At most one of coarse_b / sum_dev.  The rows the passes read must hold valid data:
  * per*mu rows beyond the range, +2 with coarse_b, +1 with sum_dev (per = 1 Jacobi, 2 RB-GS),
- * and with coarse_e the coarse rows around them. */
+ * and with coarse_e the coarse rows around them.
+ * zero_in != 0 : the input iterate is known to be all zero (PS:613: the guess of a coarse-grid correction) and
+ *                is NOT read - nobody has to write those zeros first; u is then scratch for the passes' ping-pong.
+ *                Not with coarse_e; MGX_ERR_INVALID when the first pass cannot synthesise its input (mu = 1). */
 MGX_API int mgx_slab_cycle(const mgx_slab* f, void* u, const void* b, void* tmp,
                            int row_lo, int row_hi, int mu, double omega, int smoother,
                            const mgx_slab* c, const void* coarse_e, void* coarse_b,
-                           int crow_lo, int crow_hi, int restrict_mode,
+                           int crow_lo, int crow_hi, int restrict_mode, int zero_in,
                            double* scratch, double* sum_dev, int* result_in_tmp, void* stream);
 /* fused residual + restriction (PS:604-611) of fine slab `f` into coarse slab
  * `c`, coarse local rows [crow_lo,crow_hi); zero_u (may be NULL) is the coarse

@@ -165,7 +165,7 @@ def lib() -> C.CDLL:
     L.mgx_slab_jacobi.argtypes = [sp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, ip, vp]
     L.mgx_slab_rbgs.argtypes = [sp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, vp]
     L.mgx_slab_cycle.argtypes = [sp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, sp, vp, vp,
-                                 C.c_int, C.c_int, C.c_int, vp, vp, ip, vp]
+                                 C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, ip, vp]
     L.mgx_slab_restrict.argtypes = [sp, vp, vp, sp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.mgx_slab_prolong.argtypes = [sp, vp, sp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.mgx_slab_residual_sumsq.argtypes = [sp, vp, vp, C.c_int, C.c_int, vp, vp, vp]

@@ -1732,7 +1732,7 @@ namespace {
 // window of rows the slab holds).  Local row numbers in, global ones to the kernel.
 template <typename T, int SM, int AR>
 int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int row_hi, int mu, double omega,
-                        const mgx_slab* c, const T* coarse_e, T* coarse_b, int crow_lo, int crow_hi, int restrict_mode,
+                        const mgx_slab* c, const T* coarse_e, T* coarse_b, int crow_lo, int crow_hi, int restrict_mode, int zero_in,
                         double* scratch, double* sum_dev, int* result_in_tmp, hipStream_t st)
 {
     constexpr bool rbgs = (SM == 1);
@@ -1774,6 +1774,8 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
         const int sw = parts[p], K = per * sw;
         const bool P = coarse_e && p == 0;
         const int Q = (p == np - 1) ? post : 0;
+        fa.zero_in = (p == 0 && zero_in) ? 1 : 0;              // PS:613: the first pass synthesises the zero guess
+        if (fa.zero_in && !rbgs && K == 1) return MGX_ERR_INVALID;      // (a stand-alone single sweep reads its input)
         // rows the later passes still consume; the norm / restriction stage of the last pass also
         // needs the result one / two rows beyond its range (it recomputes those rows itself, from
         // this pass's output)
@@ -1798,7 +1800,7 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
                 if (Q == 2) blocks = rc;
             } else if (!rbgs && K == 1) {
                 if (launch_jacobi<T>(src, b, dst, N, pitch, lo, hi, omega, env_int("MGX_ROWS", 0), st, f->rows, AR)) return MGX_ERR_INVALID;
-            } else if (!launch_fused<T, SM, AR>(K, src, b, dst, N, pitch, lo, hi, c0, c1, first - 1, last, f->row0 & 1, R, st, f->rows, 0)) {
+            } else if (!launch_fused<T, SM, AR>(K, src, b, dst, N, pitch, lo, hi, c0, c1, first - 1, last, f->row0 & 1, R, st, f->rows, fa.zero_in)) {
                 return MGX_ERR_INVALID;
             }
         }
@@ -1816,8 +1818,9 @@ extern "C" {
 
 int mgx_slab_cycle(const mgx_slab* f, void* u, const void* b, void* tmp, int row_lo, int row_hi, int mu, double omega,
                    int smoother, const mgx_slab* c, const void* coarse_e, void* coarse_b, int crow_lo, int crow_hi,
-                   int restrict_mode, double* scratch, double* sum_dev, int* result_in_tmp, void* stream)
+                   int restrict_mode, int zero_in, double* scratch, double* sum_dev, int* result_in_tmp, void* stream)
 {
+    if (zero_in && coarse_e) return MGX_ERR_INVALID;
     if (slab_check(f) || !u || !b || !tmp || mu < 1 || mu > 64 || row_hi <= row_lo) return MGX_ERR_INVALID;
     if ((coarse_e || coarse_b) && (slab_check(c) || c->level != f->level - 1 || c->dtype != f->dtype)) return MGX_ERR_INVALID;
     if (coarse_b && sum_dev) return MGX_ERR_INVALID;
@@ -1829,7 +1832,7 @@ int mgx_slab_cycle(const mgx_slab* f, void* u, const void* b, void* tmp, int row
     const bool rbgs = (smoother == MGX_SMOOTHER_RBGS);
 #define MGX_SLAB_CYCLE(T, SM, AR)                                                                                       \
     slab_cycle_t<T, SM, AR>(f, (T*)u, (const T*)b, (T*)tmp, row_lo, row_hi, mu, omega, c, (const T*)coarse_e, (T*)coarse_b, \
-                            crow_lo, crow_hi, restrict_mode, scratch, sum_dev, result_in_tmp, st)
+                            crow_lo, crow_hi, restrict_mode, zero_in, scratch, sum_dev, result_in_tmp, st)
     const bool fma = f->arith == MGX_ARITH_FMA;
     if (f->dtype == MGX_DTYPE_F64)
         return rbgs ? MGX_SLAB_CYCLE(double, 1, 0) : (fma ? MGX_SLAB_CYCLE(double, 0, 1) : MGX_SLAB_CYCLE(double, 0, 0));

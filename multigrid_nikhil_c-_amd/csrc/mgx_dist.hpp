@@ -39,6 +39,7 @@ struct DistSlab {
     double *scratch = nullptr, *sum_dev = nullptr, *sum_host = nullptr;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     std::vector<mgx_dist_op> ops;
+    std::vector<char> zero_pending;          // per level: the guess is an implicit zero (PS:613) the next pre-smoothing pass synthesises
 };
 
 } // namespace
@@ -58,6 +59,7 @@ struct mgx_dist {
     mgx_transport ext{};
     long exchanges = 0;
     long overlapped = 0;                     // exchanges that ran beside the interior rows of the pass they feed
+    int zero_in = 1;                         // MGX_ZERO_IN: coarse guesses are implicit zeros (no memset per level and cycle)
     int overlap = 0;                         // MGX_DIST_OVERLAP (off by default: DESIGN.md §7, the bands cost more than the exchange)
     double fine_updates = 0.0;
     // profiling of the finest-level smoothing blocks of the first local slab (cfg.profile)
@@ -231,6 +233,7 @@ int dist_create(mgx_solver* s, const mgx_config* cfg, int rank, int world, const
         return s->fail(MGX_ERR_INVALID, "no level above cut_level to distribute (use a single-GPU handle)");
     const bool fold = env_int("MGX_DIST_FOLD", 1) != 0, deep = env_int("MGX_DIST_DEEP", 1) != 0;
     d->overlap = env_int("MGX_DIST_OVERLAP", 0);
+    d->zero_in = env_int("MGX_ZERO_IN", 1);
     const int first = multi_process ? rank : 0, count = multi_process ? 1 : P;
     d->slabs.resize(count);
     for (int i = 0; i < count; ++i) {
@@ -241,6 +244,7 @@ int dist_create(mgx_solver* s, const mgx_config* cfg, int rank, int world, const
         if (dev >= ndev) return s->fail(MGX_ERR_INVALID, "device ordinal out of range");
         sl.device = dev;
         if (sl.plan.init(plan_cfg_of(*cfg, P, sl.g, d->cut, fold, deep)) != MGX_OK) return s->fail(MGX_ERR_INVALID, sl.plan.err);
+        sl.zero_pending.assign(cfg->finest_level - d->cut, 0);
     }
     for (auto& sl : d->slabs) {
         int rc = dist_alloc_slab(s, d, sl);
@@ -471,7 +475,7 @@ int dist_block_launches(const mgx_dist* d, int N, int mu, int post, bool pre = f
 // the CYCLE operation of a plan on local rows [row_lo,row_hi) of its range, on `stream` (the whole
 // range normally; the interior rows and the two edge bands separately when a halo exchange overlaps it)
 int dist_cycle_rows(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op& o, int row_lo, int row_hi, hipStream_t stream,
-                    int* flag)
+                    int* flag, int zero_in = 0)
 {
     const int cut = d->cut;
     const int dt = d->f64 ? MGX_DTYPE_F64 : MGX_DTYPE_F32;
@@ -490,7 +494,7 @@ int dist_cycle_rows(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op&
         else { cs = slab_of(d, sl.plan.L(o.level - 1)); cb = buf(sl, o.level - 1).b; }
     }
     const int rc = mgx_slab_cycle(&fs, lb.u, lb.b, lb.tmp, row_lo, row_hi, o.mu, d->cfg.omega, d->cfg.smoother,
-                                  (o.pre || o.post == 1) ? &cs : nullptr, ce, cb, o.crow_lo, o.crow_hi, d->cfg.restrict_mode,
+                                  (o.pre || o.post == 1) ? &cs : nullptr, ce, cb, o.crow_lo, o.crow_hi, d->cfg.restrict_mode, zero_in,
                                   o.post == 2 ? sl.scratch : nullptr, o.post == 2 ? sl.sum_dev : nullptr, flag, (void*)stream);
     if (rc != MGX_OK) return s->fail(rc, "mgx_slab_cycle failed on a slab");
     return MGX_OK;
@@ -537,15 +541,33 @@ int dist_local_op(mgx_solver* s, mgx_dist* d, DistSlab& sl, const mgx_dist_op& o
     const bool timed = d->cfg.profile && (&sl == &d->slabs[0]) && o.level == d->cfg.finest_level;
     switch (o.op) {
         case MGX_DOP_ZERO_U: {
+            // PS:613.  The zeros are synthesised by the pre-smoothing pass that consumes them (nobody writes or
+            // reads them: the memsets were 79 us of a 870 us cycle per GPU at 8 slabs of 16384^2) when that pass is
+            // the next operation on this level's u and is a fused / folded kernel; otherwise they are written now.
             DistLevelBuf& lb = buf(sl, o.level);
-            DCHK(s, hipMemsetAsync(lb.u, 0, lb.bytes, sl.st));
+            const size_t me = (size_t)(&o - sl.ops.data());
+            bool implicit = d->zero_in != 0 && me < sl.ops.size();
+            if (implicit) {
+                implicit = false;
+                for (size_t k = me + 1; k < sl.ops.size(); ++k) {
+                    const mgx_dist_op& n = sl.ops[k];
+                    if (n.level != o.level) continue;
+                    if (n.op == MGX_DOP_EXCHANGE && n.which == MGX_VEC_B) continue;          // the right-hand side's halos
+                    implicit = n.op == MGX_DOP_CYCLE && n.pre == 0 && (n.mu >= 2 || d->cfg.smoother == MGX_SMOOTHER_RBGS);
+                    break;
+                }
+            }
+            if (implicit) sl.zero_pending[o.level - (cut + 1)] = 1;
+            else DCHK(s, hipMemsetAsync(lb.u, 0, lb.bytes, sl.st));
             return MGX_OK;
         }
         case MGX_DOP_CYCLE: {
             DistProf pr(d, sl, timed, MGX_PROF_SMOOTH_FINE, o.mu);
             pr.launches(dist_block_launches(d, sl.plan.L(o.level).N, o.mu, o.post, o.pre != 0));
             int flag = 0;
-            const int rc = dist_cycle_rows(s, d, sl, o, o.row_lo, o.row_hi, sl.st, &flag);
+            const int zin = sl.zero_pending[o.level - (cut + 1)];
+            sl.zero_pending[o.level - (cut + 1)] = 0;
+            const int rc = dist_cycle_rows(s, d, sl, o, o.row_lo, o.row_hi, sl.st, &flag, zin);
             if (rc != MGX_OK) return rc;
             if (flag) std::swap(buf(sl, o.level).u, buf(sl, o.level).tmp);
             return MGX_OK;
@@ -662,21 +684,24 @@ int dist_run(mgx_solver* s, mgx_dist* d, double* norm_out)
                         const mgx_dist_op& c = sl.ops[j];
                         int a, b, f = 0, r = MGX_OK;
                         (void)dist_interior_rows(d, sl, c, &a, &b);
-                        if (a > c.row_lo) r = dist_cycle_rows(s, d, sl, c, c.row_lo, a, xst, &f);
-                        if (r == MGX_OK && b < c.row_hi) r = dist_cycle_rows(s, d, sl, c, b, c.row_hi, xst, &f);
+                        const int zin = sl.zero_pending[c.level - (d->cut + 1)];       // (three launches, one implicit-zero input)
+                        if (a > c.row_lo) r = dist_cycle_rows(s, d, sl, c, c.row_lo, a, xst, &f, zin);
+                        if (r == MGX_OK && b < c.row_hi) r = dist_cycle_rows(s, d, sl, c, b, c.row_hi, xst, &f, zin);
                         return r;
                     };
                     auto interior = [&](DistSlab& sl) {
                         const mgx_dist_op& c = sl.ops[j];
                         int a, b;
                         (void)dist_interior_rows(d, sl, c, &a, &b);
-                        return dist_cycle_rows(s, d, sl, c, a, b, sl.st, &flags[&sl - &d->slabs[0]]);
+                        return dist_cycle_rows(s, d, sl, c, a, b, sl.st, &flags[&sl - &d->slabs[0]], sl.zero_pending[c.level - (d->cut + 1)]);
                     };
                     rc = dist_exchange(s, d, o, true, bands, interior);
                 }
                 if (rc != MGX_OK) break;
-                for (auto& sl : d->slabs)
+                for (auto& sl : d->slabs) {
+                    sl.zero_pending[sl.ops[j].level - (d->cut + 1)] = 0;
                     if (flags[&sl - &d->slabs[0]]) std::swap(buf(sl, sl.ops[j].level).u, buf(sl, sl.ops[j].level).tmp);
+                }
                 if (d->slabs[0].ops[j].level == Lf) {
                     const double n = (double)((1 << Lf) - 1);
                     d->fine_updates += (double)d->slabs[0].ops[j].mu * n * n;

@@ -391,7 +391,12 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
             // the fewest rounds of 2048 waves with chunks of at most ~200 rows, and in that many rounds the
             // shortest chunks that fit
             bool found = false;
-            for (int m = 1; m <= 64 && !found; ++m) {
+            // MGX_MIN_ROUNDS: a launch of exactly ONE round of waves (every SIMD starts its two waves together and
+            // never gets a third) runs ~25 % slower per row step than a launch of two or more rounds (8192^2 in one
+            // round of 328-row chunks: 0.50 ms against 0.39 ms in two rounds of 164, for 6 % less work)
+            static const int min_rounds = std::max(1, env_int("MGX_MIN_ROUNDS", 1));
+            static const int min_rounds_rows = env_int("MGX_MIN_ROUNDS_ROWS", 1024);    // ... for ranges at least this high
+            for (int m = (row_hi - row_lo >= min_rounds_rows ? min_rounds : 1); m <= 64 && !found; ++m) {
                 for (int r = trip_rows(16, 2 * K + E, kTripSteps, 2); r <= 204; r += kTripSteps) {
                     const CycleGeom c = cycle_geom(row_lo, row_hi, strips, r, edge_short ? edge_rows(r, 2 * K + E, kTripSteps) : r,
                                                    edge_short ? last_rows(r, 2 * K + E, kTripSteps) : r);

@@ -169,6 +169,24 @@ def test_multi_gpu_handle_device_fills_and_unsupported_calls(pkg):
         pkg.Multigrid(n_gpus=8, devices=[0] * 8, cut_level=6, finest_level=9, coarsest_level=5, mu1=10, mu2=10, schedule=0)
 
 
+@pytest.mark.parametrize("P,smoother,mu1,mu2", [(4, "jacobi", 10, 10), (2, "rbgs", 2, 1), (2, "jacobi", 1, 1), (8, "jacobi", 3, 2)])
+def test_implicit_zero_guesses_on_the_slab_levels_change_no_bit(pkg, po, monkeypatch, P, smoother, mu1, mu2):
+    """PS:613: the coarse guesses of the distributed levels are not written and read back (MGX_ZERO_IN=1, the
+    default: the first pre-smoothing pass synthesises them; mu1 = 1 falls back to the memset) - same bits as
+    with the memsets (MGX_ZERO_IN=0) and as the single-GPU solve"""
+    c = dict(finest=11, coarsest=6, mu1=mu1, mu2=mu2, smoother=smoother)
+    b, u0 = _problem(po, c)
+    h_ref, u_ref = _single(pkg, c, b, u0, 3)
+    for zin in ("1", "0"):
+        monkeypatch.setenv("MGX_ZERO_IN", zin)
+        with pkg.Multigrid(n_gpus=P, devices=[0] * P, cut_level=7, **_cfg(pkg, c)) as mg:
+            mg.set_rhs(b)
+            mg.set_guess(u0)
+            st, h = mg.solve(tol=0.0, max_cycles=3)
+            assert np.array_equal(mg.get_solution(), u_ref), zin
+            assert np.allclose(h, h_ref, rtol=1e-13, atol=0)
+
+
 def test_rank_handle_with_the_builtin_rccl_transport_at_world_one(pkg, po):
     """ncclCommInitRank, ncclAllGather and ncclAllReduce really run (one rank: RCCL refuses two on one
     device); same bits as the single-GPU solve"""

@@ -162,15 +162,17 @@ def test_slab_cycle_equals_the_separate_slab_operators(pkg, po, dt, smoother, mu
     cs = pkg.Slab(level=level - 1, dtype=code, rows=chi - clo, row0=clo)
     scratch = hm.zeros(int(L.mgx_slab_scratch_doubles(C.byref(fs))), np.float64)
 
-    def run(pre, post, rl, rh):
+    def run(pre, post, rl, rh, zero_in=0):
         u, b, tmp = U[lo:hi].clone(), B[lo:hi].clone(), hm.zeros_like(U[lo:hi])
+        if zero_in:                                       # the call must not read u: poison it
+            u = hm.from_numpy(np.full(u.shape, np.nan, dtype=dt))
         ce = E[clo:chi].clone()
         cb = hm.zeros_like(ce)
         out = hm.zeros(1, np.float64)
         flag = C.c_int()
         st = L.mgx_slab_cycle(C.byref(fs), u.data_ptr(), b.data_ptr(), tmp.data_ptr(), rl - lo, rh - lo, mu, 2.0 / 3.0, kind,
                               C.byref(cs), ce.data_ptr() if pre else None, cb.data_ptr() if post == 1 else None,
-                              own_lo // 2 - clo, own_hi // 2 - clo, 0, scratch.data_ptr() if post == 2 else None,
+                              own_lo // 2 - clo, own_hi // 2 - clo, 0, zero_in, scratch.data_ptr() if post == 2 else None,
                               out.data_ptr() if post == 2 else None, C.byref(flag), None)
         hm.synchronize()
         return st, (tmp if flag.value else u).cpu().numpy(), cb.cpu().numpy(), float(out.item())
@@ -197,3 +199,12 @@ def test_slab_cycle_equals_the_separate_slab_operators(pkg, po, dt, smoother, mu
     r = po.residual(ref, f)[own_lo - 1:own_hi - 1].astype(np.float64)
     assert abs(sq - float(np.sum(r * r))) <= 1e-12 * float(np.sum(r * r))
     assert np.array_equal(got[own_lo - lo:own_hi - lo, 1:N], ref[own_lo - 1:own_hi - 1])
+    # zero_in: the guess of a coarse-grid correction (PS:613) is synthesised, not read
+    st, got, cb, _ = run(False, 1, own_lo - 1, own_hi + 1, zero_in=1)
+    assert st == 0
+    ref = sm(np.zeros_like(v), f, mu)
+    assert np.array_equal(got[own_lo - 1 - lo:own_hi + 1 - lo, 1:N], ref[own_lo - 2:own_hi])
+    rr = po.restrict(po.residual(ref, f))
+    assert np.array_equal(cb[own_lo // 2 - clo:own_hi // 2 - clo, 1:NC], rr[own_lo // 2 - 1:own_hi // 2 - 1])
+    st, *_ = run(True, 0, own_lo, own_hi, zero_in=1)
+    assert st != 0                                   # a correction is added to an iterate that exists
