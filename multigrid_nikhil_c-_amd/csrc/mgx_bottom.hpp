@@ -8,7 +8,7 @@
 // type-I discrete sine transform: with S_jk = sqrt(2/(n+1)) sin(pi j k/(n+1))
 // (symmetric, S S = I) and lambda_ij = 4 sin^2(pi i/2(n+1)) + 4 sin^2(pi j/2(n+1)),
 //     U = S ( (S B S) ./ lambda ) S .
-// n <= 255, so the four n^3 products are ~8 MFLOP: four small launches, always
+// n <= 255, so the four n^3 products are ~8 MFLOP: two small launches of two products each, always
 // in double whatever the level's storage type.  This is a direct solver (no
 // iteration, no tolerance); the oracle uses banded Cholesky, an independent
 // exact method, so agreement between the two checks both.
@@ -20,74 +20,80 @@
 
 namespace mgx {
 
-// C = op(A * B): one thread per output, k-loop in registers.
-//  IN_GRID : B (step 1) is the level's padded grid of type T, element (k,j) at (k+1, j+1)
-//  OUT_GRID: C (step 4) is written to the padded grid of type T
-//  SCALE   : multiply by 1 / (s[i] + s[j])   (step 2)
-template <typename T, bool IN_GRID, bool OUT_GRID, bool SCALE>
+// Two of the four products per launch.  U = S ((S B S) ./ lambda) S is two row-local pairs - row i of (S B) S needs
+// only row i of S B, row i of (S T) S only row i of S T - so one workgroup owns output row i: its threads j first form
+// P[i][j] = sum_k S[i][k] X[k][j] (X the level's grid b, or the scaled transform T of the first launch), park the row
+// in LDS, and then form sum_k P[i][k] S[k][j].  Every sum runs in k order with one accumulator, exactly the four
+// products of the oracle's ORC_BOTTOM_DST (same bits as the four-launch form of rounds 1-2: 4 x 9 us -> 2 launches).
+//  FIRST: X is the padded grid of type T (element (k, j) at (k + 1, j + 1)); the result is divided by
+//         s[i] + s[j] and written to the n x n double array `out`
+//  else : X is the n x n double array; the result is written to the padded grid of type T
+template <typename T, bool FIRST>
 __global__ void __launch_bounds__(256)
-k_dst_gemm(const double* __restrict__ A, const void* __restrict__ Bv, void* __restrict__ Cv,
-           const double* __restrict__ s, int n, long gpitch)
+k_dst_pair(const double* __restrict__ S, const void* __restrict__ Xv, void* __restrict__ Ov, const double* __restrict__ s,
+           int n, long gpitch)
 {
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-    // the row index is the same for a whole wave: as a scalar, row i of A is read through the scalar
-    // cache (s_load) and costs no vector memory instruction
-    const int i = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (i >= n || j >= n) return;
-    // The sum runs in k order with one accumulator (deterministic); the loads are independent of
-    // it, so they are issued kDeep at a time: a 127-term dot product is nothing but L2 latency
-    // (8 deep: 16 round trips, 10.5 us per product; 32 deep: 4).
+    __shared__ double prow[256];
+    const int j = threadIdx.x;
+    const int i = blockIdx.x;                       // wave-uniform: row i of S goes through the scalar cache
+    const bool live = j < n;
+    // the loads of a sum are independent of its accumulator: they are issued kDeep at a time (a 127-term dot
+    // product is nothing but L2 latency otherwise)
     constexpr int kDeep = 32;
+    const double* Sr = S + (long)i * n;
     double acc = 0.0;
-    const double* Ar = A + (long)i * n;
-    int k = 0;
-    if (IN_GRID) {
-        const T* B = reinterpret_cast<const T*>(Bv) + gpitch + (j + 1);
+    {
+        int k = 0;
         for (; k + kDeep <= n; k += kDeep) {
-            double b[kDeep];
+            double x[kDeep];
 #pragma unroll
-            for (int q = 0; q < kDeep; ++q) b[q] = (double)B[(long)(k + q) * gpitch];
+            for (int q = 0; q < kDeep; ++q) {
+                if constexpr (FIRST) x[q] = live ? (double)(reinterpret_cast<const T*>(Xv)[(long)(k + q + 1) * gpitch + (j + 1)]) : 0.0;
+                else x[q] = live ? reinterpret_cast<const double*>(Xv)[(long)(k + q) * n + j] : 0.0;
+            }
 #pragma unroll
-            for (int q = 0; q < kDeep; ++q) acc += Ar[k + q] * b[q];
+            for (int q = 0; q < kDeep; ++q) acc += Sr[k + q] * x[q];
         }
-        {
-            // the remainder, fetched together as well (rows beyond n - 1 are not read)
-            double b[kDeep];
+        double x[kDeep];
 #pragma unroll
-            for (int q = 0; q < kDeep; ++q) b[q] = (k + q < n) ? (double)B[(long)(k + q) * gpitch] : 0.0;
-#pragma unroll
-            for (int q = 0; q < kDeep; ++q)
-                if (k + q < n) acc += Ar[k + q] * b[q];
+        for (int q = 0; q < kDeep; ++q) {
+            const bool ok = live && (k + q < n);
+            if constexpr (FIRST) x[q] = ok ? (double)(reinterpret_cast<const T*>(Xv)[(long)(k + q + 1) * gpitch + (j + 1)]) : 0.0;
+            else x[q] = ok ? reinterpret_cast<const double*>(Xv)[(long)(k + q) * n + j] : 0.0;
         }
-    } else {
-        const double* B = reinterpret_cast<const double*>(Bv) + j;
-        for (; k + kDeep <= n; k += kDeep) {
-            double b[kDeep];
 #pragma unroll
-            for (int q = 0; q < kDeep; ++q) b[q] = B[(long)(k + q) * n];
-#pragma unroll
-            for (int q = 0; q < kDeep; ++q) acc += Ar[k + q] * b[q];
-        }
-        {
-            double b[kDeep];
-#pragma unroll
-            for (int q = 0; q < kDeep; ++q) b[q] = (k + q < n) ? B[(long)(k + q) * n] : 0.0;
-#pragma unroll
-            for (int q = 0; q < kDeep; ++q)
-                if (k + q < n) acc += Ar[k + q] * b[q];
-        }
+        for (int q = 0; q < kDeep; ++q)
+            if (k + q < n) acc += Sr[k + q] * x[q];
     }
-    if (SCALE) acc = acc / (s[i] + s[j]);
-    if (OUT_GRID) reinterpret_cast<T*>(Cv)[(long)(i + 1) * gpitch + (j + 1)] = (T)acc;
-    else reinterpret_cast<double*>(Cv)[(long)i * n + j] = acc;
+    prow[j] = acc;
+    __syncthreads();
+    double out = 0.0;
+    {
+        int k = 0;
+        for (; k + kDeep <= n; k += kDeep) {
+            double x[kDeep];
+#pragma unroll
+            for (int q = 0; q < kDeep; ++q) x[q] = live ? S[(long)(k + q) * n + j] : 0.0;
+#pragma unroll
+            for (int q = 0; q < kDeep; ++q) out += prow[k + q] * x[q];
+        }
+        double x[kDeep];
+#pragma unroll
+        for (int q = 0; q < kDeep; ++q) x[q] = (live && k + q < n) ? S[(long)(k + q) * n + j] : 0.0;
+#pragma unroll
+        for (int q = 0; q < kDeep; ++q)
+            if (k + q < n) out += prow[k + q] * x[q];
+    }
+    if (!live) return;
+    if constexpr (FIRST) reinterpret_cast<double*>(Ov)[(long)i * n + j] = out / (s[i] + s[j]);
+    else reinterpret_cast<T*>(Ov)[(long)(i + 1) * gpitch + (j + 1)] = (T)out;
 }
 
 struct BottomDST {
     int n = 0;
     double* S = nullptr;      // n x n sine matrix
     double* s = nullptr;      // n eigenvalue halves: 4 sin^2(pi (i+1) / (2 (n+1)))
-    double* w1 = nullptr;     // n x n work
-    double* w2 = nullptr;
+    double* w1 = nullptr;     // n x n: (S B S) ./ lambda between the two launches
 
     hipError_t init(int n_)
     {
@@ -109,7 +115,6 @@ struct BottomDST {
         if ((e = hipMalloc(&S, nn * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&s, n * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&w1, nn * sizeof(double))) != hipSuccess) return e;
-        if ((e = hipMalloc(&w2, nn * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMemcpy(S, hS.data(), nn * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return e;
         if ((e = hipMemcpy(s, hs.data(), n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return e;
         return hipSuccess;
@@ -120,20 +125,15 @@ struct BottomDST {
         if (S) (void)hipFree(S);
         if (s) (void)hipFree(s);
         if (w1) (void)hipFree(w1);
-        if (w2) (void)hipFree(w2);
-        S = s = w1 = w2 = nullptr;
+        S = s = w1 = nullptr;
     }
 
-    // u_grid = A^-1 b_grid on the padded coarsest-level grids (4 launches)
+    // u_grid = A^-1 b_grid on the padded coarsest-level grids (2 launches; w1 holds (S B S) ./ lambda in between)
     template <typename T>
     void solve(const T* b_grid, T* u_grid, long gpitch, hipStream_t st) const
     {
-        const dim3 blk(256);
-        const dim3 grd((n + 63) / 64, (n + 3) / 4);
-        hipLaunchKernelGGL((k_dst_gemm<T, true, false, false>), grd, blk, 0, st, S, (const void*)b_grid, (void*)w1, s, n, gpitch);
-        hipLaunchKernelGGL((k_dst_gemm<T, false, false, true>), grd, blk, 0, st, w1, (const void*)S, (void*)w2, s, n, gpitch);
-        hipLaunchKernelGGL((k_dst_gemm<T, false, false, false>), grd, blk, 0, st, S, (const void*)w2, (void*)w1, s, n, gpitch);
-        hipLaunchKernelGGL((k_dst_gemm<T, false, true, false>), grd, blk, 0, st, w1, (const void*)S, (void*)u_grid, s, n, gpitch);
+        hipLaunchKernelGGL((k_dst_pair<T, true>), dim3(n), dim3(256), 0, st, S, (const void*)b_grid, (void*)w1, s, n, gpitch);
+        hipLaunchKernelGGL((k_dst_pair<T, false>), dim3(n), dim3(256), 0, st, S, (const void*)w1, (void*)u_grid, s, n, gpitch);
     }
 };
 

@@ -1235,7 +1235,15 @@ constexpr int ring_slot(int m) { return ((m % kBRing) + kBRing) % kBRing; }
 // register-hungry kernels of the library, a step of theirs is ~800 vector instructions long, and two
 // rows in flight keep them at two waves per SIMD without spills.
 // (the deep edge bodies, with their masks on top, too: the 10-level correction pass spilled with three)
-template <bool BL, int POST, bool EDGE = false> constexpr int cycle_pfd() { return (BL && (POST == 1 || EDGE)) ? 2 : kPrefetch; }
+#ifndef MGX_PFD_DEEP
+#define MGX_PFD_DEEP 0      // experiment knob: rows in flight in the interior bodies of the deep passes (0: 2 with the restriction stage, else 3)
+#endif
+template <bool BL, int POST, bool EDGE = false> constexpr int cycle_pfd()
+{
+    if (BL && !EDGE && MGX_PFD_DEEP > 0) return MGX_PFD_DEEP;
+    return (BL && (POST == 1 || EDGE)) ? 2 : kPrefetch;
+}
+constexpr int kPrefetchMax = MGX_PFD_DEEP > kPrefetch ? MGX_PFD_DEEP : kPrefetch;
 // rows the coarse correction (PRE) is fetched ahead.  vmcnt counts in issue order, so waiting for a
 // coarse row fetched ONE step ago also waits for every fine row issued before it: with a one-step
 // coarse prefetch the three-row fine prefetch was worth one row.  The interior bodies fetch the
@@ -1544,7 +1552,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         // (the deep bodies round their step count up to whole kBRing-step trips)
         constexpr int kRound = BL ? kBRing : trip_steps<T>();
         const int y_first = r0 - K - ETOP - 1;
-        const int y_lastp = (r0 - K - ETOP) + ((r1 + K + EBOT) - (r0 - K - ETOP) + kRound - 1) / kRound * kRound + kPrefetch;
+        const int y_lastp = (r0 - K - ETOP) + ((r1 + K + EBOT) - (r0 - K - ETOP) + kRound - 1) / kRound * kRound + kPrefetchMax;
         bool interior = (vx0 >= 1) && ((long)(vx0 + kWave + 1) * W < N) &&
                         (y_first > 0) && (y_lastp < N) && (y_first >= win.row_first) && (y_lastp <= win.row_last);
         if (PRE) interior = interior && (y_first >> 1) >= win.crow_first && ((y_lastp >> 1) + 1) <= win.crow_last;
