@@ -12,7 +12,7 @@ Rendezvous: rank 0 hosts the store.  The launcher may name its port (MGX_RDZV_PO
 ephemeral port and publishes it in a file named after the launcher's pid and MASTER_PORT (every
 rank of a job is a child of the same launcher process on this one node).
 
-Every blocking call has a deadline (default 120 s, MGX_RDZV_TIMEOUT): a rank that died never makes
+Every blocking call has a deadline (default 600 s, MGX_RDZV_TIMEOUT: a cold start of the first rank - libraries paged in, a 16384^2 reference run - must fit): a rank that died never makes
 the others wait for the launcher's outer timeout."""
 from __future__ import annotations
 
@@ -128,7 +128,7 @@ class Store:
     def __init__(self, rank: int | None = None, world: int | None = None, timeout: float | None = None):
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
-        self.timeout = float(os.environ.get("MGX_RDZV_TIMEOUT", "120")) if timeout is None else timeout
+        self.timeout = float(os.environ.get("MGX_RDZV_TIMEOUT", "600")) if timeout is None else timeout
         self._seq = 0
         self._p2p: dict[tuple[int, int], int] = {}
         self._server = None
