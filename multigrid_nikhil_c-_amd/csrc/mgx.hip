@@ -1649,12 +1649,14 @@ int mgx_time_smoother(mgx_handle s, int sweeps, double* ms)
 {
     if (!s || !ms || sweeps < 1) return MGX_ERR_INVALID;
     NO_DIST(s)
+    if (int vr = var_ready(s, s->cfg.finest_level, s->cfg.finest_level)) return vr;
     hipEvent_t a, b;
     HIPCHK(s, hipEventCreate(&a));
     HIPCHK(s, hipEventCreate(&b));
     Level& l = s->lv[s->cfg.finest_level];
     HIPCHK(s, hipEventRecord(a, s->stream));
-    if (l.f64) smooth_t<double>(s, l, sweeps); else smooth_t<float>(s, l, sweeps);
+    if (s->var) { if (l.f64) smooth_var_t<double>(s, l, sweeps); else smooth_var_t<float>(s, l, sweeps); }
+    else if (l.f64) smooth_t<double>(s, l, sweeps); else smooth_t<float>(s, l, sweeps);
     HIPCHK(s, hipEventRecord(b, s->stream));
     HIPCHK(s, hipEventSynchronize(b));
     float f = 0.f;
