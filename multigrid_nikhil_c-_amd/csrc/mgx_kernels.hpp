@@ -1205,6 +1205,26 @@ cycle_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
 constexpr int kBRing = 12;                     // >= K + 1 for K <= 10, multiple of the 3 rotation phases
 // (float: from 10 levels - the 8-level float bodies fit their registers with the window in them and keep 3-step trips)
 template <typename T, int K, int POST, int SM> constexpr bool cycle_b_in_lds() { return (sizeof(T) == 8 && K >= 8) || (sizeof(T) == 4 && K >= 10); }
+// Two level chains per step (round 3; built, bit-identical, measured, OFF).  A row step of a K-level pass is a serial
+// chain: level j needs level j-1's row of this very step, ten times over, and a wave's two points per lane are all the
+// independent work there is; the counters (profiles/r03a_sq_summary.md: vector ALU busy 0.64-0.67 with 1.6 waves per
+// SIMD, a third of the wave time stalled on issue) suggested more instruction-level parallelism.  With a SKEW the upper
+// levels run ONE STEP BEHIND: levels SK+1 .. K of step y work on rows y-j-1 from what level SK left in its window at step
+// y-1, so chains A = levels 1..SK and B = levels SK+1..K of one step are independent and their instructions interleave.
+// Cost: one more row step per chunk, one more row of level SK alive, one more entry of the rhs delay line.  Same
+// operations on the same values in the same order: same bits (188 parity tests).  Measured against the serial chain inside
+// one GPU call: 8192^2 pass 0.412-0.418 against 0.386-0.413 ms, 16384^2 1.48 against 1.51, 4096^2 equal: the second wave
+// of the SIMD already fills what a lone chain leaves, so it stays off (-DMGX_SKEW=1 builds it).
+#ifndef MGX_SKEW
+#define MGX_SKEW 0
+#endif
+template <typename T, int K, int PRE, int POST, int SM, int AR> constexpr int cycle_skew()
+{
+    // (not where the interleaved chains' registers do not fit: these two variants would spill 16-24 B)
+    if (sizeof(T) == 8 && K == 10 && PRE == 1 && POST == 0 && SM == 0 && AR == 0) return 0;
+    if (sizeof(T) == 4 && K == 10 && PRE == 0 && POST == 1 && SM == 0) return 0;
+    return (MGX_SKEW != 0 && cycle_b_in_lds<T, K, POST, SM>()) ? K / 2 : 0;
+}
 template <typename T> struct LdsVec;
 template <> struct LdsVec<double> { typedef double v __attribute__((ext_vector_type(2))); };
 template <> struct LdsVec<float> { typedef float v __attribute__((ext_vector_type(4))); };
@@ -1333,33 +1353,32 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     // instructions in front of its consumer, and the ~100-cycle LDS latency sat exposed in every one
     // of the K levels of the serial level-to-level chain.
     constexpr int kRingAhead = 1;
-    constexpr int MLAST = POST ? K : K - 1;           // last window entry this step consumes
-    V rq[BL ? K + 1 : 1];                              // BL: ring values in flight (a sliding window is live)
-    if constexpr (BL) {
-        static_for<1, (kRingAhead < MLAST ? kRingAhead : MLAST) + 1>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            rq[m] = ring_get(ring, ring_slot(RP - m));
-        });
-    }
+    constexpr int SK = cycle_skew<T, K, PRE, POST, SM, AR>();      // 0: one serial chain of K levels; else levels SK+1..K run one step behind
+    constexpr int SKD = SK > 0 ? 1 : 0;
+    constexpr int MLAST = (POST ? K : K - 1) + SKD;   // last window entry this step consumes
+    V rq[BL ? K + 2 : 1];                              // BL: ring values in flight (a sliding window is live)
     auto bwin = [&](auto jc) -> V {
         constexpr int j = decltype(jc)::value;
         if constexpr (j == 0) return b0;
         else if constexpr (BL) return rq[j];
         else return bw[j];
     };
+    // the row of level SK that dies in this step (its slot takes the new row): chain B's first level still needs it
+    V dying = lev[SK][S_NEW];
     lev[0][S_NEW] = in;
-    static_for<1, K + 1>([&](auto jc) {
+    // level j of this step: row y-j (chain A / no skew) or y-j-1 (chain B) from level j-1's window and rhs row `row`
+    auto level = [&](auto jc, auto bc) {
         constexpr int j = decltype(jc)::value;
-        const int row = y - j;
-        if constexpr (BL && j + kRingAhead <= MLAST) {
-            rq[j + kRingAhead] = ring_get(ring, ring_slot(RP - (j + kRingAhead)));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const V cb = bwin(std::integral_constant<int, j - 1>{});
+        constexpr bool inB = decltype(bc)::value;
+        const int row = y - j - (inB ? 1 : 0);
+        const V cb = bwin(std::integral_constant<int, j - 1 + (inB ? 1 : 0)>{});
+        // (oldest, middle, newest) rows of level j-1: chain B's first level reads them as they stood BEFORE this step
+        const V& lo = (inB && j == SK + 1) ? dying : lev[j - 1][S_OLD];
+        const V& mi = (inB && j == SK + 1) ? lev[j - 1][S_OLD] : lev[j - 1][S_MID];
+        const V& hi = (inB && j == SK + 1) ? lev[j - 1][S_MID] : lev[j - 1][S_NEW];
         V o;
-        if constexpr (PREMUL) o = jacobi_vec_pre<AR>(lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], cb, c0, c1);
-        else o = level_op<T, SM, AR>(j, lev[j - 1][S_OLD], lev[j - 1][S_MID], lev[j - 1][S_NEW], cb, c0, c1,
-                                 row + (int)(col & 1));
+        if constexpr (PREMUL) o = jacobi_vec_pre<AR>(lo, mi, hi, cb, c0, c1);
+        else o = level_op<T, SM, AR>(j, lo, mi, hi, cb, c0, c1, row + (int)(col & 1));
         if constexpr (EDGE) {                                                      // Dirichlet rows and columns stay zero
             const int rw = opaque_s(row);
             mask_sel(o, cm, !(rw > bnd_lo && rw < bnd_hi));
@@ -1369,11 +1388,42 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
             bstore(o, fo.out, (st && row >= r0 && row < r1) ? at : kOobOffset);
         }
         if (j < K || POST) lev[j][S_NEW] = o;
-    });
+    };
+    if constexpr (SK == 0) {
+        if constexpr (BL) {
+            static_for<1, (kRingAhead < MLAST ? kRingAhead : MLAST) + 1>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                rq[m] = ring_get(ring, ring_slot(RP - m));
+            });
+        }
+        static_for<1, K + 1>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (BL && j + kRingAhead <= MLAST) {
+                rq[j + kRingAhead] = ring_get(ring, ring_slot(RP - (j + kRingAhead)));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            level(jc, std::false_type{});
+        });
+    } else {
+        // pairs (A_i, B_i) = (level i, level SK + i): independent of each other inside a pair, so the scheduler
+        // interleaves them; the ring entries of the next pair (A: row y-1-i, B: row y-1-(SK+i+1)) are fetched a pair ahead
+        constexpr int NB = K - SK;
+        constexpr int NP = SK > NB ? SK : NB;
+        rq[SK + 1] = ring_get(ring, ring_slot(RP - (SK + 1)));                 // B_1's rhs row (A_1 uses b0)
+        static_for<1, NP + 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i + 1 <= SK) rq[i] = ring_get(ring, ring_slot(RP - i));                          // A_(i+1): bwin(i)
+            if constexpr (i + 1 <= NB) rq[SK + i + 1] = ring_get(ring, ring_slot(RP - (SK + i + 1)));    // B_(i+1)
+            if constexpr (POST != 0 && i == NP) rq[K + 1] = ring_get(ring, ring_slot(RP - (K + 1)));       // the residual stage's row
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i <= SK) level(std::integral_constant<int, i>{}, std::false_type{});
+            if constexpr (i <= NB) level(std::integral_constant<int, SK + i>{}, std::true_type{});
+        });
+    }
     if (POST) {
-        // residual of the new iterate on row rho = y-K-1 (rows rho-1, rho, rho+1 of level K)
-        const int rho = y - K - 1;
-        V res = residual_vec(lev[K][S_OLD], lev[K][S_MID], lev[K][S_NEW], bwin(std::integral_constant<int, K>{}));
+        // residual of the new iterate on row rho = y-K-1 (rows rho-1, rho, rho+1 of level K; one step later with the skew)
+        const int rho = y - K - 1 - SKD;
+        V res = residual_vec(lev[K][S_OLD], lev[K][S_MID], lev[K][S_NEW], bwin(std::integral_constant<int, K + SKD>{}));
         if constexpr (EDGE) {
             const int rw = opaque_s(rho);
             mask_sel(res, cm, !(rw > bnd_lo && rw < bnd_hi));
@@ -1456,7 +1506,7 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     CycleArgs ca;
     ca.cpitch = cpitch; ca.NC = N / 2; ca.r0 = r0; ca.r1 = r1; ca.zero_in = zero_in; ca.win = win;
     const int y0 = r0 - K - ETOP;
-    ca.y_end = r1 + K + EBOT;                       // exclusive end of the steps that matter
+    ca.y_end = r1 + K + EBOT + (cycle_skew<T, K, PRE, POST, SM, AR>() > 0 ? 1 : 0);      // exclusive end of the steps that matter
     // rounded up to whole rotations; the deep (BL) bodies run whole kBRing-step trips with no exit in
     // between - a branch-free trip is what lets the compiler keep several rows in flight - and the
     // launcher picks the chunk height so that nothing (or one step) is wasted
@@ -1552,7 +1602,8 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         // (the deep bodies round their step count up to whole kBRing-step trips)
         constexpr int kRound = BL ? kBRing : trip_steps<T>();
         const int y_first = r0 - K - ETOP - 1;
-        const int y_lastp = (r0 - K - ETOP) + ((r1 + K + EBOT) - (r0 - K - ETOP) + kRound - 1) / kRound * kRound + kPrefetchMax;
+        constexpr int SKD = cycle_skew<T, K, PRE, POST, SM, AR>() > 0 ? 1 : 0;            // the skewed chain's extra step
+        const int y_lastp = (r0 - K - ETOP) + ((r1 + K + EBOT + SKD) - (r0 - K - ETOP) + kRound - 1) / kRound * kRound + kPrefetchMax;
         bool interior = (vx0 >= 1) && ((long)(vx0 + kWave + 1) * W < N) &&
                         (y_first > 0) && (y_lastp < N) && (y_first >= win.row_first) && (y_lastp <= win.row_last);
         if (PRE) interior = interior && (y_first >> 1) >= win.crow_first && ((y_lastp >> 1) + 1) <= win.crow_last;

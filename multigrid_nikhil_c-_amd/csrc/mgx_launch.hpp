@@ -370,7 +370,7 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
 {
     constexpr int OUT = cycle_out_lanes<K, POST, VecOf<T>::W>();
     constexpr bool BL = cycle_b_in_lds<T, K, POST, SM>();
-    constexpr int E = POST == 1 ? 3 : (POST == 2 ? 2 : 0);
+    constexpr int E = (POST == 1 ? 3 : (POST == 2 ? 2 : 0)) + (cycle_skew<T, K, PRE, POST, SM, AR>() > 0 ? 1 : 0);   // row steps of a chunk beyond R + 2K
     constexpr int kTripSteps = BL ? kBRing : trip_steps<T>();
     const bool whole = (fa.row_hi == 0);
     const int row_lo = whole ? 1 : fa.row_lo, row_hi = whole ? N : fa.row_hi;
