@@ -1571,7 +1571,9 @@ int mgx_solve(mgx_handle s, double tol, int max_cycles, mgx_stats* stats, double
                 Prof p(s, MGX_PROF_NORM_FINE, 2);
                 if (pending_scale != 0.0) {
                     // the correction and the residual in one out-of-place pass (32 instead of 40 B per point)
-                    Launch gr = make_launch(d.N, 2, d.N - 1, rpc);
+                    // rows per wave of this pass (MGX_MIXED_ROWS; 0: the marching default of make_launch)
+                    static const int mixed_rows = env_int("MGX_MIXED_ROWS", 0);
+                    Launch gr = make_launch(d.N, 2, d.N - 1, mixed_rows > 0 ? mixed_rows : rpc);
                     if (gr.blocks > s->partial_cap) {
                         const int R = (int)(((long)gr.strips * (d.N - 1) / kWavesPerBlock + s->partial_cap - 9) / (s->partial_cap - 8)) + 1;
                         gr = make_launch(d.N, 2, d.N - 1, R);

@@ -1218,6 +1218,9 @@ template <typename T, int K, int POST, int SM> constexpr bool cycle_b_in_lds() {
 #ifndef MGX_SKEW
 #define MGX_SKEW 0
 #endif
+#ifndef MGX_PRIO_ALT
+#define MGX_PRIO_ALT 0      // experiment knob (round 3, within noise): the two waves of a SIMD alternate at the higher issue priority, trip by trip
+#endif
 template <typename T, int K, int PRE, int POST, int SM, int AR> constexpr int cycle_skew()
 {
     // (not where the interleaved chains' registers do not fit: these two variants would spill 16-24 B)
@@ -1534,7 +1537,23 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
 #define MGX_CTRIP(Y) do { MGX_CSTEP(0, Y); MGX_CSTEP(1, Y + 1); MGX_CSTEP(2, Y + 2); MGX_CSTEP(3, Y + 3); MGX_CSTEP(4, Y + 4); \
                           MGX_CSTEP(5, Y + 5); MGX_CSTEP(6, Y + 6); MGX_CSTEP(7, Y + 7); MGX_CSTEP(8, Y + 8); MGX_CSTEP(9, Y + 9); \
                           MGX_CSTEP(10, Y + 10); MGX_CSTEP(11, Y + 11); } while (0)
+#if MGX_PRIO_ALT
+        // The SIMD's issue arbiter serves the OLDER of its two waves first: in the wave trace of a two-round launch one
+        // wave of every pair finishes after 159 us, its partner after 235 us, the second round starts staggered by that
+        // much and the launch ends with a fifth of its span at less than half occupancy.  The two waves of a SIMD (hardware
+        // wave slots of opposite parity) therefore take turns at the higher priority, one 12-step trip each.
+        unsigned hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        int turn = (int)(hw_id & 1u);
+        for (int y = y0; y < y0 + steps; y += kBRing) {
+            if (turn & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            turn ^= 1;
+            MGX_CTRIP(y);
+        }
+        __builtin_amdgcn_s_setprio(0);
+#else
         for (int y = y0; y < y0 + steps; y += kBRing) MGX_CTRIP(y);
+#endif
 #undef MGX_CTRIP
     } else if constexpr (trip_steps<T>() == 12) {
         for (int y = y0; y < y0 + steps; y += 12) {

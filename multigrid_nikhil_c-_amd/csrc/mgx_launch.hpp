@@ -394,10 +394,11 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
             // MGX_MIN_ROUNDS: a launch of exactly ONE round of waves (every SIMD starts its two waves together and
             // never gets a third) runs ~25 % slower per row step than a launch of two or more rounds (8192^2 in one
             // round of 328-row chunks: 0.50 ms against 0.39 ms in two rounds of 164, for 6 % less work)
+            static const int min_chunk = std::max(8, env_int("MGX_MIN_CHUNK", 16));          // shortest chunk considered
             static const int min_rounds = std::max(1, env_int("MGX_MIN_ROUNDS", 1));
             static const int min_rounds_rows = env_int("MGX_MIN_ROUNDS_ROWS", 1024);    // ... for ranges at least this high
             for (int m = (row_hi - row_lo >= min_rounds_rows ? min_rounds : 1); m <= 64 && !found; ++m) {
-                for (int r = trip_rows(16, 2 * K + E, kTripSteps, 2); r <= 204; r += kTripSteps) {
+                for (int r = trip_rows(min_chunk, 2 * K + E, kTripSteps, 2); r <= 204; r += kTripSteps) {
                     const CycleGeom c = cycle_geom(row_lo, row_hi, strips, r, edge_short ? edge_rows(r, 2 * K + E, kTripSteps) : r,
                                                    edge_short ? last_rows(r, 2 * K + E, kTripSteps) : r);
                     if (c.waves <= 2048L * m) { g = c; found = true; break; }

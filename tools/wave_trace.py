@@ -18,7 +18,8 @@ class WT(C.Structure):
     _fields_ = [("t0", C.c_longlong), ("t1", C.c_longlong), ("strip", C.c_int), ("r0", C.c_int), ("r1", C.c_int), ("hw", C.c_int)]
 
 
-with pkg.Multigrid(finest_level=L, coarsest_level=L - 1 if L <= 8 else 7, mu0=0, mu1=10, mu2=10, schedule=0, profile=1) as mg:
+with pkg.Multigrid(finest_level=L, coarsest_level=L - 1 if L <= 8 else 7, mu0=0, mu1=10, mu2=10, schedule=0, profile=1,
+                   arith=pkg.ARITH_FMA) as mg:
     mg.fill_rhs(1, 0.0)
     mg.fill_guess_random(1)
     mg.solve(tol=0.0, max_cycles=3)
@@ -35,6 +36,13 @@ end = (act[:, 1] - t0) / 100.0
 dur = end - start
 rows = act[:, 4] - act[:, 3]
 print(f"L{L}: {len(act)} active waves of {n}; kernel span {end.max():.1f} us")
+# how full were the 2048 wave slots (256 CUs x 4 SIMDs x 2 waves) over the launch?
+span = end.max()
+print(f"  slot occupancy: sum of wave durations / (2048 slots x span) = {dur.sum() / (2048 * span):.3f}; "
+      f"resident waves at 5 % steps of the span: " +
+      " ".join(str(int(((start <= t) & (end > t)).sum())) for t in np.linspace(0.025, 0.975, 20) * span))
+steps = rows + 23
+print(f"  us per row step by start time: first round (start < 5 us) {np.median((dur / steps)[start < 5]):.3f}, later {np.median((dur / steps)[start >= 5]):.3f}")
 print(f"  wave start: min {start.min():.1f}  median {np.median(start):.1f}  p90 {np.percentile(start, 90):.1f}  max {start.max():.1f} us")
 print(f"  wave end  : min {end.min():.1f}  median {np.median(end):.1f}  p90 {np.percentile(end, 90):.1f}  max {end.max():.1f} us")
 print(f"  duration  : min {dur.min():.1f}  median {np.median(dur):.1f}  p90 {np.percentile(dur, 90):.1f}  max {dur.max():.1f} us")
