@@ -2,7 +2,8 @@
   * mgx_create(cfg.n_gpus = P) with every slab on device 0 must reproduce the single-GPU mgx_solve
     bit for bit at P = 2, 4, 8 (same kernels on row ranges, halos carrying the neighbour's values);
   * mgx_create_rank: one process per rank, two and four ranks sharing the GPU over the host-staged
-    gloo transport (RCCL refuses two ranks on one device), same bits again;
+    transport of the job's TCP store (RCCL refuses two ranks on one device), same bits again, and every rank process
+    on ONE ROCm stack (the one libmgx is built against);
   * the built-in RCCL transport at world 1 (communicator, all-gather, all-reduce really run);
   * the PS-shaped C++ driver binary with an n_gpus argument."""
 import os
