@@ -172,3 +172,35 @@ def test_configurations_the_path_does_not_support_are_refused(pkg):
         mg.set_stencil(6, *[np.ones((63, 63))] * 5)
         with pytest.raises(pkg.MgxError, match="level 4 not set"):
             mg.vcycle(6)
+
+
+def test_seeded_fuzz_of_general_operator_configurations(pkg, po):
+    """16 random configurations (fixed seed) of the general-operator path: levels, sweeps, weights, restriction
+    modes, schedules, bottom modes, random positive coefficients - histories against the oracle to 1e-10"""
+    rng = np.random.default_rng(20261005)
+    for case in range(16):
+        finest = int(rng.integers(5, 10))
+        coarsest = int(rng.integers(2, min(5, finest) + 1))
+        cfg = dict(finest_level=finest, coarsest_level=coarsest, mu0=int(rng.integers(0, 2)), mu1=int(rng.integers(0, 5)),
+                   mu2=int(rng.integers(0, 5)), omega=float(rng.choice([2.0 / 3.0, 0.8, 0.6])), schedule=int(rng.integers(0, 2)),
+                   restrict_mode=int(rng.choice([0, 0, 3, 2, 1])), bottom=int(rng.choice([0, 0, 1])), op=VAR)
+        if cfg["mu1"] + cfg["mu2"] == 0:
+            cfg["mu2"] = 2
+        n = (1 << finest) - 1
+        x = np.linspace(0.0, 1.0, n + 2)
+        a = np.exp(rng.uniform(-0.7, 0.7) * np.sin(rng.integers(1, 4) * np.pi * x)[None, :] * np.cos(rng.integers(1, 4) * np.pi * x)[:, None])
+        a = a * (1.0 + 0.1 * rng.random(a.shape))
+        b = po.rhs_sine(finest) if case % 2 else po.rhs_constant(finest)
+        u0 = po.fill_uniform((n, n), 500 + case) if cfg["schedule"] == 0 and case % 3 == 0 else None
+        with pkg.Multigrid(**cfg) as mg:
+            mg.set_coefficient(a)
+            mg.set_rhs(b)
+            if u0 is not None:
+                mg.set_guess(u0)
+            st, h = mg.solve(tol=1e-9, max_cycles=6)
+            u = mg.get_solution()
+        ref = po.Solver(**cfg)
+        ref.set_coefficient(a)
+        u_ref, h_ref = ref.solve(b, u0, tol=1e-9, max_cycles=6)
+        assert hist_close(h, h_ref), (case, cfg, h, h_ref)
+        assert np.max(np.abs(u - u_ref)) <= 1e-10 * max(np.max(np.abs(u_ref)), 1e-300), (case, cfg)
