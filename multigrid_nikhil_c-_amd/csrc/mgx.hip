@@ -1772,6 +1772,25 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
         if (coarse_b) fa.coarse_b = coarse_b - (long)c->row0 * fa.cpitch;
     }
     const long back = (long)f->row0 * pitch;
+    // Small slab ranges (2048^2 slabs of 256 rows at 8 GPUs, the edge bands of an overlapped exchange): a marching pass is
+    // latency-bound there - R + 2K row steps one after the other, however few rows - and the register-tile kernel does
+    // the whole block in one launch of independent tiles.  Same arithmetic in the same order: same bits.
+    {
+        static const long tile_points = env_int("MGX_SLAB_TILE_POINTS", 1 << 20);
+        const int lo = std::max(std::max(row_lo, first), 1), hi = std::min(std::min(row_hi, last), f->rows - 1);
+        if (fc.tile_max_n > 0 && per * mu <= fc.tile_k && hi > lo && (long)(hi - lo) * N <= tile_points) {
+            FoldArgs ta = fa;
+            ta.row_lo = lo + f->row0; ta.row_hi = hi + f->row0;
+            int flips = 0;
+            const int nb = smooth_tiled<T, SM, AR>(u - back, b - back, tmp - back, N, pitch, mu, omega, fc.tile_k, ta, coarse_e != nullptr,
+                                                   post, zero_in != 0, st, &flips);
+            if (nb >= 0) {
+                if (post == 2) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kReduceThreads), 0, st, scratch, nb, sum_dev);
+                if (result_in_tmp) *result_in_tmp = flips & 1;
+                return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_HIP;
+            }
+        }
+    }
     T* src = u; T* dst = tmp;
     int done = 0, blocks = 0;
     for (int p = 0; p < np; ++p) {
@@ -1825,6 +1844,8 @@ int mgx_slab_cycle(const mgx_slab* f, void* u, const void* b, void* tmp, int row
                    int restrict_mode, int zero_in, double* scratch, double* sum_dev, int* result_in_tmp, void* stream)
 {
     if (zero_in && coarse_e) return MGX_ERR_INVALID;
+    // the folded restriction wants its range to start on an odd global row (include/mgx.h) - whichever kernel serves the call
+    if (coarse_b && !((std::max(row_lo + f->row0, 1)) & 1)) return MGX_ERR_INVALID;
     if (slab_check(f) || !u || !b || !tmp || mu < 1 || mu > 64 || row_hi <= row_lo) return MGX_ERR_INVALID;
     if ((coarse_e || coarse_b) && (slab_check(c) || c->level != f->level - 1 || c->dtype != f->dtype)) return MGX_ERR_INVALID;
     if (coarse_b && sum_dev) return MGX_ERR_INVALID;

@@ -1719,7 +1719,7 @@ __global__ void __launch_bounds__(kBlock)
 k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restrict__ vout,
               const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
               double* __restrict__ partial, int N, long pitch, long cpitch, int levels, T c0, T c1,
-              int tiles_x, int zero_in)
+              int tiles_x, int zero_in, int row_lo, int row_hi, CycleWin win)
 {
     constexpr int RW = kTileBand;
     __shared__ T edge[2][kWavesPerBlock][2][kWave];     // [buffer][wave][first / last row][lane]
@@ -1730,7 +1730,9 @@ k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restric
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = wv * RW;                         // array row of this wave's register row 0
-    const int gy0 = 1 + ty * TH - He + y0;          // its global node row
+    // rows [row_lo, row_hi) are updated (whole grid: 1 .. N-1); on a slab of a row-decomposed grid the base pointers
+    // are moved back so that GLOBAL row numbers index them, and `win` says which rows (and coarse rows) exist
+    const int gy0 = row_lo + ty * TH - He + y0;     // its global node row
     const int gx = 1 + tx * TW - He + lane;         // this lane's global node column
     const bool colunk = gx > 0 && gx < N;
     const int NC = N / 2;
@@ -1741,8 +1743,9 @@ k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restric
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int gy = gy0 + i;
-        if (gy > 0 && gy < N) rowmask |= 1u << i;
-        const bool unk = colunk && gy > 0 && gy < N;
+        const bool rowok = gy > 0 && gy < N && gy >= win.row_first && gy <= win.row_last;     // wave-uniform
+        if (rowok) rowmask |= 1u << i;
+        const bool unk = colunk && rowok;
         const long at = (long)gy * pitch + gx;
         u[i] = (unk && !zero_in) ? vin[at] : (T)0;
         b[i] = unk ? rhs[at] : (T)0;
@@ -1752,8 +1755,8 @@ k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restric
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             const int gy = gy0 + i;
-            const bool unk = colunk && gy > 0 && gy < N;
             const bool rodd = (gy & 1) != 0;                               // wave-uniform
+            const bool unk = colunk && ((rowmask >> i) & 1u) && (gy >> 1) >= win.crow_first && (gy >> 1) + (rodd ? 1 : 0) <= win.crow_last;
             // the four coarse nodes around (gy, gx); all inside the coarse grid when (gy, gx) is an unknown
             const T* e = coarse_e + (long)(gy >> 1) * cpitch + (gx >> 1);
             const T a00 = unk ? e[0] : (T)0;
@@ -1810,7 +1813,7 @@ k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restric
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int y = y0 + i, gy = gy0 + i;
-        if (y >= He && y < He + TH && gy < N && colout) vout[(long)gy * pitch + gx] = u[i];
+        if (y >= He && y < He + TH && gy < N && gy >= row_lo && gy < row_hi && colout) vout[(long)gy * pitch + gx] = u[i];
     }
 
     if (POST != 0) {
@@ -1829,7 +1832,7 @@ k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restric
             T rr = (T)0;
             if (colunk && gy > 0 && gy < N) rr = b[i] - (-nbr(prev, l, r, below) + (T)4 * cur);
             res[i] = rr;
-            if (POST == 2 && y >= He && y < He + TH && colout) acc += (double)rr * (double)rr;
+            if (POST == 2 && y >= He && y < He + TH && gy >= row_lo && gy < row_hi && colout) acc += (double)rr * (double)rr;
             prev = cur;
         }
         if (POST == 2) {
@@ -1861,7 +1864,8 @@ k_tile_smooth(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restric
                 edges = edges + n;
                 edges = edges + s2;
                 const T o = wgt * ((corners + (T)2 * edges) + (T)4 * c);
-                if (cst && y >= He && y < He + TH && (gy & 1) == 0 && gy < N) {     // a coarse row of this tile
+                if (cst && y >= He && y < He + TH && (gy & 1) == 0 && gy < N && gy >= row_lo && gy < row_hi &&
+                    (gy >> 1) >= win.emit_lo && (gy >> 1) < win.emit_hi) {          // a coarse row of this tile
                     const long at = (long)(gy >> 1) * cpitch + J;
                     coarse_b[at] = o;
                     if (coarse_zero) coarse_zero[at] = (T)0;

@@ -474,11 +474,16 @@ int launch_tile(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N, lo
     const int He = levels + tile_extra<POST>();
     const int TH = kTileSY - 2 * He, TW = kTileSX - 2 * He;
     if (TH < 8 || TW < 8) return -1;
-    const int tiles_y = (N - 1 + TH - 1) / TH, tiles_x = (N - 1 + TW - 1) / TW;
+    // whole grid (fa.row_hi == 0), or rows [row_lo, row_hi) of a slab whose base pointers were moved back by row0 rows
+    const bool whole = (fa.row_hi == 0);
+    const int row_lo = whole ? 1 : fa.row_lo, row_hi = whole ? N : fa.row_hi;
+    const CycleWin win = whole ? CycleWin{0, N, 0, N / 2, 1, N / 2} : fa.win;
+    const int tiles_y = (row_hi - row_lo + TH - 1) / TH, tiles_x = (N - 1 + TW - 1) / TW;
+    if (tiles_y < 1) return 0;
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
     hipLaunchKernelGGL((k_tile_smooth<T, SM, PRE, POST, AR>), dim3(tiles_y * tiles_x), dim3(kBlock), 0, st, vin, b, vout,
                        (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
-                       levels, c0, c1, tiles_x, fa.zero_in);
+                       levels, c0, c1, tiles_x, fa.zero_in, row_lo, row_hi, win);
     return tiles_y * tiles_x;
 }
 
