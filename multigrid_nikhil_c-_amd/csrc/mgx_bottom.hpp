@@ -18,6 +18,10 @@
 #include <cmath>
 #include <vector>
 
+#ifndef MGX_DST_DEEP
+#define MGX_DST_DEEP 32
+#endif
+
 namespace mgx {
 
 // Two of the four products per launch.  U = S ((S B S) ./ lambda) S is two row-local pairs - row i of (S B) S needs
@@ -38,8 +42,8 @@ k_dst_pair(const double* __restrict__ S, const void* __restrict__ Xv, void* __re
     const int i = blockIdx.x;                       // wave-uniform: row i of S goes through the scalar cache
     const bool live = j < n;
     // the loads of a sum are independent of its accumulator: they are issued kDeep at a time (a 127-term dot
-    // product is nothing but L2 latency otherwise)
-    constexpr int kDeep = 32;
+    // product is nothing but L2 latency otherwise; 64 deep measured slower: 98 against 86 us for the coarse part of the reference hierarchy)
+    constexpr int kDeep = MGX_DST_DEEP;
     const double* Sr = S + (long)i * n;
     double acc = 0.0;
     {

@@ -1218,6 +1218,9 @@ template <typename T, int K, int POST, int SM> constexpr bool cycle_b_in_lds() {
 #ifndef MGX_SKEW
 #define MGX_SKEW 0
 #endif
+#ifndef MGX_RING_AHEAD
+#define MGX_RING_AHEAD 1     // levels a ring entry is fetched ahead of its use
+#endif
 #ifndef MGX_PRIO_ALT
 #define MGX_PRIO_ALT 0      // experiment knob (round 3, within noise): the two waves of a SIMD alternate at the higher issue priority, trip by trip
 #endif
@@ -1228,6 +1231,15 @@ template <typename T, int K, int PRE, int POST, int SM, int AR> constexpr int cy
     if (sizeof(T) == 4 && K == 10 && PRE == 0 && POST == 1 && SM == 0) return 0;
     return (MGX_SKEW != 0 && cycle_b_in_lds<T, K, POST, SM>()) ? K / 2 : 0;
 }
+// The rhs window holds c1 * b (one multiplication per point and step instead of one per point, step and LEVEL: 18 of the
+// ~200 vector instructions of a 10-level row step); the residual stage of POST needs b itself, K steps after it was
+// loaded: a second delay line, kRawLds steps deep in LDS (a ring of its own: 24 KiB per workgroup, two workgroups still
+// fit a CU's 160 KiB) and K - kRawLds steps in registers.  Same values into the same operations: same bits.
+constexpr int kRawLds = 6;                     // divides kBRing: every slot a compile-time offset
+#ifndef MGX_RAWQ
+#define MGX_RAWQ 1
+#endif
+template <typename T, int K, int PRE, int POST, int SM, int AR> constexpr bool cycle_rawq();
 template <typename T> struct LdsVec;
 template <> struct LdsVec<double> { typedef double v __attribute__((ext_vector_type(2))); };
 template <> struct LdsVec<float> { typedef float v __attribute__((ext_vector_type(4))); };
@@ -1253,6 +1265,13 @@ __device__ __forceinline__ float4 ring_get(lds_vec_ptr<float> r, int slot)
     return make_float4(t.x, t.y, t.z, t.w);
 }
 constexpr int ring_slot(int m) { return ((m % kBRing) + kBRing) % kBRing; }
+template <typename T, int K, int PRE, int POST, int SM, int AR> constexpr bool cycle_rawq()
+{
+    if (MGX_RAWQ == 0) return false;
+    if (PRE != 0 || sizeof(T) != 8) return false;     // (registers: <double,10,1,2> would spill 76 B with the delay line)
+    if (POST == 2 && AR == 0 && K == 10) return false;  // (12 B)
+    return cycle_b_in_lds<T, K, POST, SM>() && SM == 0 && POST != 0 && K > kRawLds && cycle_skew<T, K, PRE, POST, SM, AR>() == 0;
+}
 // rows a folded pass loads ahead of itself (one register slot pair per row in flight).  Three
 // everywhere, except the deep pre-smoothing passes with the restriction stage: they are the most
 // register-hungry kernels of the library, a step of theirs is ~800 vector instructions long, and two
@@ -1280,6 +1299,7 @@ template <typename T, bool BL, bool EDGE, int POST> constexpr int cycle_cpfd() {
 template <typename T, int K, int PRE, int POST, int SM, bool EDGE, int RP, bool BL, bool ZIN, int AR>
 __device__ __forceinline__ void
 cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&bw)[BL ? 1 : K + 1], lds_vec_ptr<T> ring,
+           lds_vec_ptr<T> ring2, typename VecOf<T>::type (&rawq)[cycle_rawq<T, K, PRE, POST, SM, AR>() ? kBRing : 1],
            typename VecOf<T>::type (&nin)[kPfStages], typename VecOf<T>::type (&nbn)[kPfStages], PreFetch<T, VecOf<T>::W / 2>& pe,   // pe: this step's slot
            CycleState<T, VecOf<T>::W / 2>& cs, int y,
            const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
@@ -1337,7 +1357,8 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     }
     // Jacobi passes without a residual stage keep c1 * b in the window (see jacobi_vec_pre);
     // the residual of POST needs b itself
-    constexpr bool PREMUL = (SM == 0 && POST == 0);
+    constexpr bool RAWQ = cycle_rawq<T, K, PRE, POST, SM, AR>();
+    constexpr bool PREMUL = (SM == 0 && POST == 0) || RAWQ;
     V b0;                                             // rhs row y-1 (times c1 when PREMUL): bw[0]
     if constexpr (PREMUL) b0 = vscale(c1, bn);
     else b0 = bn;
@@ -1346,6 +1367,13 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
         // every offset being a constant): make the address opaque once per step
         asm volatile("" : "+v"(ring));
         ring_put(ring, ring_slot(RP), b0);
+        if constexpr (RAWQ) {
+            // b itself, for the residual stage K steps from now: kRawLds steps in the second ring (read the slot's old
+            // content - rhs row y-1-kRawLds - before overwriting it: LDS operations of a wave complete in order), the rest in registers
+            asm volatile("" : "+v"(ring2));
+            rawq[ring_slot(RP)] = ring_get(ring2, RP % kRawLds);
+            ring_put(ring2, RP % kRawLds, bn);
+        }
     } else {
 #pragma unroll
         for (int j = K; j > 0; --j) bw[j] = bw[j - 1];
@@ -1355,10 +1383,10 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     // their use and pinned there: left to itself the compiler sinks every ds_read_b128 to ~5
     // instructions in front of its consumer, and the ~100-cycle LDS latency sat exposed in every one
     // of the K levels of the serial level-to-level chain.
-    constexpr int kRingAhead = 1;
+    constexpr int kRingAhead = MGX_RING_AHEAD;
     constexpr int SK = cycle_skew<T, K, PRE, POST, SM, AR>();      // 0: one serial chain of K levels; else levels SK+1..K run one step behind
     constexpr int SKD = SK > 0 ? 1 : 0;
-    constexpr int MLAST = (POST ? K : K - 1) + SKD;   // last window entry this step consumes
+    constexpr int MLAST = ((POST && !RAWQ) ? K : K - 1) + SKD;   // last window entry this step consumes
     V rq[BL ? K + 2 : 1];                              // BL: ring values in flight (a sliding window is live)
     auto bwin = [&](auto jc) -> V {
         constexpr int j = decltype(jc)::value;
@@ -1426,7 +1454,10 @@ cycle_step(typename VecOf<T>::type (&lev)[K + 1][3], typename VecOf<T>::type (&b
     if (POST) {
         // residual of the new iterate on row rho = y-K-1 (rows rho-1, rho, rho+1 of level K; one step later with the skew)
         const int rho = y - K - 1 - SKD;
-        V res = residual_vec(lev[K][S_OLD], lev[K][S_MID], lev[K][S_NEW], bwin(std::integral_constant<int, K + SKD>{}));
+        V rawb;                                       // rhs row rho
+        if constexpr (RAWQ) rawb = rawq[ring_slot(RP - (K - kRawLds))];
+        else rawb = bwin(std::integral_constant<int, K + SKD>{});
+        V res = residual_vec(lev[K][S_OLD], lev[K][S_MID], lev[K][S_NEW], rawb);
         if constexpr (EDGE) {
             const int rw = opaque_s(rho);
             mask_sel(res, cm, !(rw > bnd_lo && rw < bnd_hi));
@@ -1481,9 +1512,10 @@ __device__ __forceinline__ double
 cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ po,
            const T* __restrict__ coarse_e, T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,
            long pitch, long cpitch, long col, int N, int r0, int r1, bool ld, bool st, T c0, T c1, bool zero_in,
-           const CycleWin& win, lds_vec_ptr<T> ring, const FastOut& fo)
+           const CycleWin& win, lds_vec_ptr<T> ring, lds_vec_ptr<T> ring2, const FastOut& fo)
 {
     constexpr bool BL = cycle_b_in_lds<T, K, POST, SM>();
+    constexpr bool RAWQ = cycle_rawq<T, K, PRE, POST, SM, AR>();
     using V = typename VecOf<T>::type;
     constexpr int W = VecOf<T>::W;
     constexpr int CW = W / 2;
@@ -1501,6 +1533,13 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
     if constexpr (BL) {
 #pragma unroll
         for (int q = 0; q < kBRing; ++q) ring_put(ring, q, Z);
+    }
+    V rawq[RAWQ ? kBRing : 1];                       // [step phase]: b on its way from the second ring to the residual stage
+#pragma unroll
+    for (int q = 0; q < (RAWQ ? kBRing : 1); ++q) rawq[q] = Z;
+    if constexpr (RAWQ) {
+#pragma unroll
+        for (int q = 0; q < kRawLds; ++q) ring_put(ring2, q, Z);
     }
     CycleState<T, CW> cs;
     cs.acc = 0.0;
@@ -1531,7 +1570,7 @@ cycle_body(const T* __restrict__ pv, const T* __restrict__ pb, T* __restrict__ p
 #pragma unroll
         for (int q = 0; q < CPFD; ++q) coarse_loads<T, EDGE>(pe[q], y0 + q, coarse_e, cpitch, ccol, N, cld, ca.win, fo);
     }
-#define MGX_CSTEP(RP, Y) cycle_step<T, K, PRE, POST, SM, EDGE, RP, BL, ZIN, AR>(lev, bw, ring, nin[(RP) % PFD], nbn[(RP) % PFD], pe[(RP) % CPFD], cs, Y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1, fo)
+#define MGX_CSTEP(RP, Y) cycle_step<T, K, PRE, POST, SM, EDGE, RP, BL, ZIN, AR>(lev, bw, ring, ring2, rawq, nin[(RP) % PFD], nbn[(RP) % PFD], pe[(RP) % CPFD], cs, Y, pv, pb, po, coarse_e, coarse_b, coarse_zero, wgt, pitch, col, ccol, N, ca, ld, cld, st, c0, c1, fo)
     if constexpr (BL) {
         // kBRing steps per trip so that every ring slot is a compile-time offset
 #define MGX_CTRIP(Y) do { MGX_CSTEP(0, Y); MGX_CSTEP(1, Y + 1); MGX_CSTEP(2, Y + 2); MGX_CSTEP(3, Y + 3); MGX_CSTEP(4, Y + 4); \
@@ -1600,6 +1639,8 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     // the waves' rhs rings (deep passes only: cycle_b_in_lds)
     constexpr bool BL = cycle_b_in_lds<T, K, POST, SM>();
     __shared__ typename LdsVec<T>::v bring[BL ? kWavesPerBlock * kBRing * kWave : 1];
+    constexpr bool RAWQ = cycle_rawq<T, K, PRE, POST, SM, AR>();
+    __shared__ typename LdsVec<T>::v braw[RAWQ ? kWavesPerBlock * kRawLds * kWave : 1];
     const CTile t = cycle_tile(strips, chunks, chunks_e, R, Re, row_lo, row_hi, row_last0, Rl);
     double acc = 0.0;
 #ifdef MGX_WAVE_TRACE
@@ -1609,6 +1650,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         const int lane = threadIdx.x & 63;
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         lds_vec_ptr<T> ring = (lds_vec_ptr<T>)&bring[BL ? (wv * kBRing * kWave + lane) : 0];
+        lds_vec_ptr<T> ring2 = (lds_vec_ptr<T>)&braw[RAWQ ? (wv * kRawLds * kWave + lane) : 0];
         const int vx0 = t.strip * OUT - HL;
         const int vx = vx0 + lane;
         const long col = (long)vx * W;
@@ -1648,13 +1690,13 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         if (interior) {
             if (PRE == 0 && zero_in)
                 acc = cycle_body<T, K, PRE, POST, SM, false, PRE == 0, AR>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
-                                                                      pitch, cpitch, col, N, r0, r1, true, st, c0, c1, true, win, ring, fo);
+                                                                      pitch, cpitch, col, N, r0, r1, true, st, c0, c1, true, win, ring, ring2, fo);
             else
                 acc = cycle_body<T, K, PRE, POST, SM, false, false, AR>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
-                                                                    pitch, cpitch, col, N, r0, r1, true, st, c0, c1, false, win, ring, fo);
+                                                                    pitch, cpitch, col, N, r0, r1, true, st, c0, c1, false, win, ring, ring2, fo);
         } else {
             acc = cycle_body<T, K, PRE, POST, SM, true, false, AR>(vin + col, rhs + col, vout + col, coarse_e, coarse_b, coarse_zero, wgt,
-                                                        pitch, cpitch, col, N, r0, r1, ld, st, c0, c1, zero_in != 0, win, ring, fo);
+                                                        pitch, cpitch, col, N, r0, r1, ld, st, c0, c1, zero_in != 0, win, ring, ring2, fo);
         }
     }
 #ifdef MGX_WAVE_TRACE

@@ -88,3 +88,29 @@ print("  waves per SIMD by XCC (min..max over its SIMDs): " +
 r0s = act[:, 3]
 print("  median first-round duration by chunk row (first 12 / last 6): " +
       " ".join(f"{int(r)}:{np.median(dur[first & (r0s == r)]):.0f}" for r in list(np.unique(r0s[first]))[:12] + list(np.unique(r0s[first]))[-6:]))
+# ---- the two first-round waves of one SIMD: how long does each take?
+pairs = collections.defaultdict(list)
+for i in np.nonzero(first)[0]:
+    pairs[(int(xcc[i]), int(key[i]), int(simd[i]))].append(i)
+two = [v for v in pairs.values() if len(v) == 2]
+if two:
+    sh_ = np.array([min(dur[a], dur[b]) for a, b in two]); lo_ = np.array([max(dur[a], dur[b]) for a, b in two])
+    st_ = np.array([steps[a] for a, b in two], dtype=float)
+    print(f"  SIMDs with exactly two first-round waves: {len(two)}; shorter wave {np.median(sh_):.1f} us, longer {np.median(lo_):.1f} us "
+          f"(median row steps {np.median(st_):.0f}: {np.median(sh_ / st_):.3f} / {np.median(lo_ / st_):.3f} us per step)")
+    lone = [v for v in pairs.values() if len(v) == 1]
+    if lone:
+        d_ = np.array([dur[v[0]] for v in lone]); s_ = np.array([steps[v[0]] for v in lone], dtype=float)
+        print(f"  SIMDs with ONE first-round wave: {len(lone)}; {np.median(d_):.1f} us, {np.median(d_ / s_):.3f} us per step")
+    # which of the two is the faster one: the lower block index?  how far apart are the two blocks of a SIMD?
+    widx = np.nonzero(a[:, 2] >= 0)[0]          # wave number = 4 * blockIdx + wave in block
+    blk = widx // 4
+    fa = np.array([(a_ if dur[a_] <= dur[b_] else b_) for a_, b_ in two]); sl = np.array([(b_ if dur[a_] <= dur[b_] else a_) for a_, b_ in two])
+    d_blk = blk[sl] - blk[fa]
+    print(f"  faster wave has the LOWER block index in {np.mean(d_blk > 0):.3f} of the pairs; block distance slow - fast: "
+          f"median {np.median(d_blk):.0f}, p10 {np.percentile(d_blk, 10):.0f}, p90 {np.percentile(d_blk, 90):.0f}; "
+          f"starts: fast {np.median(start[fa]):.2f} us, slow {np.median(start[sl]):.2f} us")
+    print(f"  block index of the faster waves: p5 {np.percentile(blk[fa], 5):.0f} median {np.median(blk[fa]):.0f} p95 {np.percentile(blk[fa], 95):.0f}; "
+          f"of the slower: p5 {np.percentile(blk[sl], 5):.0f} median {np.median(blk[sl]):.0f} p95 {np.percentile(blk[sl], 95):.0f}")
+    hwslot = hw & 15
+    print(f"  hardware wave slot of the faster: {np.bincount(hwslot[fa], minlength=10)[:10]}, of the slower: {np.bincount(hwslot[sl], minlength=10)[:10]}")
