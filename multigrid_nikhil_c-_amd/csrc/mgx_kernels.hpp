@@ -109,6 +109,9 @@ __device__ __forceinline__ double from_right(double x)
 // bodies therefore contain no branch at all: stores go through a raw buffer descriptor and a lane
 // or row that must not store gets an offset beyond the descriptor's range (the hardware drops it),
 // conditional accumulations are selects, and "the input is all zero" is a template parameter.
+#ifndef MGX_SOFF_LOADS
+#define MGX_SOFF_LOADS 1    // interior bodies load through the buffer descriptors with a scalar row offset
+#endif
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef int v2i32 __attribute__((ext_vector_type(2)));
 constexpr unsigned kOobOffset = 0xFFFFFF00u;       // beyond every descriptor here (arrays < 4 GiB - 256 B)
@@ -156,6 +159,28 @@ __device__ __forceinline__ float4 bload(float4*, __amdgpu_buffer_rsrc_t r, unsig
 {
     const v4i32 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
     return make_float4(__int_as_float(t.x), __int_as_float(t.y), __int_as_float(t.z), __int_as_float(t.w));
+}
+// the same with the row part of the address as a SCALAR offset (the instruction's soffset operand): the interior bodies
+// address row y of a lane's column as descriptor + lane offset (one VGPR, constant) + (y - rb) * pitch (one s_mul_i32)
+// instead of a 64-bit pointer sum per load (five scalar multiplies / adds and a 64-bit vector add each)
+__device__ __forceinline__ double2 bload_s(double2*, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const v4i32 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_double2(__hiloint2double(t.y, t.x), __hiloint2double(t.w, t.z));
+}
+__device__ __forceinline__ float4 bload_s(float4*, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const v4i32 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__int_as_float(t.x), __int_as_float(t.y), __int_as_float(t.z), __int_as_float(t.w));
+}
+__device__ __forceinline__ double bload1_s(double*, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const v2i32 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double(t.y, t.x);
+}
+__device__ __forceinline__ float bload1_s(float*, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 __device__ __forceinline__ double bload1(double*, __amdgpu_buffer_rsrc_t r, unsigned voff)
 {
@@ -665,9 +690,16 @@ fused_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
     using V = typename VecOf<T>::type;
     if constexpr (!EDGE) {
         // interior body: no predicate, no branch (see "branch-free stores" above)
+#if MGX_SOFF_LOADS
+        const unsigned srow = (unsigned)(y - fo.rb) * fo.pitch_bytes;
+        if constexpr (ZIN) in = vzero((V*)nullptr);
+        else in = bload_s((V*)nullptr, fo.in, fo.lane_off, srow);
+        bn = bload_s((V*)nullptr, fo.rhs, fo.lane_off, srow - fo.pitch_bytes);
+#else
         if constexpr (ZIN) in = vzero((V*)nullptr);
         else in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
         bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
+#endif
     } else {
         // edge body: no branch either (see "branch-free loads" above).
         // [rd_lo, rd_hi]: rows inside the allocation and not beyond a boundary row;
@@ -1151,6 +1183,14 @@ coarse_loads(PreFetch<T, VecOf<T>::W / 2>& pe, int y, const T* __restrict__ coar
     constexpr int CW = VecOf<T>::W / 2;
     const int I = y >> 1;
     if constexpr (!EDGE) {
+#if MGX_SOFF_LOADS
+        const unsigned srow = (unsigned)(I - fo.crb) * fo.cpitch_bytes;
+#pragma unroll
+        for (int k = 0; k <= CW; ++k) pe.a[k] = bload1_s((T*)nullptr, fo.ce, fo.clane_off + (unsigned)(k * sizeof(T)), srow);
+        // the row below is only used by odd fine rows; loading it always keeps the step branch-free
+#pragma unroll
+        for (int k = 0; k <= CW; ++k) pe.b[k] = bload1_s((T*)nullptr, fo.ce, fo.clane_off + (unsigned)(k * sizeof(T)), srow + fo.cpitch_bytes);
+#else
         const T* p = coarse_e + (long)I * cpitch + ccol;
 #pragma unroll
         for (int k = 0; k <= CW; ++k) pe.a[k] = p[k];
@@ -1158,6 +1198,7 @@ coarse_loads(PreFetch<T, VecOf<T>::W / 2>& pe, int y, const T* __restrict__ coar
         const T* q = p + cpitch;
 #pragma unroll
         for (int k = 0; k <= CW; ++k) pe.b[k] = q[k];
+#endif
     } else {
         const bool cl = cld && y > 0 && y < N && I >= win.crow_first && I + (y & 1) <= win.crow_last;
         const bool cl2 = cl && (y & 1);
@@ -1179,9 +1220,16 @@ cycle_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
     using V = typename VecOf<T>::type;
     if constexpr (!EDGE) {
         // interior body: no predicate, no branch (ZIN: the input is known to be all zero)
+#if MGX_SOFF_LOADS
+        const unsigned srow = (unsigned)(y - fo.rb) * fo.pitch_bytes;
+        if constexpr (ZIN) in = vzero((V*)nullptr);
+        else in = bload_s((V*)nullptr, fo.in, fo.lane_off, srow);
+        bn = bload_s((V*)nullptr, fo.rhs, fo.lane_off, srow - fo.pitch_bytes);
+#else
         if constexpr (ZIN) in = vzero((V*)nullptr);
         else in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
         bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
+#endif
     } else {
         // edge body: no branch either - a row or lane that must not be read reads 0 through the
         // descriptor (win.row_first >= 0 and win.row_last <= N: the window also keeps y inside the grid)

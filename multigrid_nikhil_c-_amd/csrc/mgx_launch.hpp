@@ -391,9 +391,9 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
             // the fewest rounds of 2048 waves with chunks of at most ~200 rows, and in that many rounds the
             // shortest chunks that fit
             bool found = false;
-            // MGX_MIN_ROUNDS: a launch of exactly ONE round of waves (every SIMD starts its two waves together and
-            // never gets a third) runs ~25 % slower per row step than a launch of two or more rounds (8192^2 in one
-            // round of 328-row chunks: 0.50 ms against 0.39 ms in two rounds of 164, for 6 % less work)
+            // MGX_MIN_ROUNDS (experiment knob, default 1): a launch of ONE round of workgroups (<= 512) is as fast per row
+            // step as one of several rounds (8192^2: one round of 348-row chunks 0.371-0.382 ms, two rounds of 168 0.374-0.377;
+            // the "25 % slower" recorded earlier for 328-row chunks was 520 workgroups, eight more than fit)
             static const int min_chunk = std::max(8, env_int("MGX_MIN_CHUNK", 16));          // shortest chunk considered
             static const int min_rounds = std::max(1, env_int("MGX_MIN_ROUNDS", 1));
             static const int min_rounds_rows = env_int("MGX_MIN_ROUNDS_ROWS", 1024);    // ... for ranges at least this high
