@@ -34,6 +34,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include "mgx_geom.hpp"
 #include <stdint.h>
 #include <type_traits>
 
@@ -285,74 +286,15 @@ struct WaveTrace { long long t0, t1; int strip, r0, r1, hw; };
 __device__ WaveTrace g_wave_trace[1 << 16];
 __device__ int g_wave_trace_n;
 #endif
-struct CTile { int strip, r0, r1; bool active; };
+// (the tile map itself is plain C++ shared with the launcher and the CPU tests: mgx_geom.hpp)
 __device__ __forceinline__ CTile cycle_tile(int strips, int chunks, int chunks_e, int R, int Re, int row_lo, int row_hi,
-                                            int row_last0, int Rl)
+                                            int row_last0, int Rl, int RB, int n_tall, int n_short)
 {
-    const int per_xcd = gridDim.x >> 3;
-    const int xcd = blockIdx.x & 7;
-    const int nth = blockIdx.x >> 3;
+    // the wave index as a scalar: everything derived from it (chunk, rows, row offsets, the row predicates) then
+    // lives in SGPRs and costs no vector instruction
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int si = strips - 2;
-    CTile t;
-    if (row_last0 != 0) {
-        // Tiles of two classes (the launcher uses this mode only with >= 3 strips and >= 3 chunks):
-        //   E: the first and the last two chunks of every interior strip, every chunk of the two edge strips -
-        //      waves that (almost certainly) run the edge body;  M: the middle chunks of the interior strips.
-        // EVERY XCD gets an eighth of each class and starts with its E tiles.  With all the E tiles at the
-        // end of one list they all landed on one XCD, two edge workgroups per CU, and ran 1.35-1.6 us per
-        // row step; next to an interior workgroup an edge wave gets the vector ALU whenever its neighbour
-        // waits.
-        const int n_edge = 3 * si + 2 * chunks_e, n_mid = (chunks - 3) * si;
-        const int pe = (n_edge + 7) >> 3, pm = (n_mid + 7) >> 3;
-        const int lw = nth * kWavesPerBlock + wave;
-        if (lw < pe) {
-            const int e = xcd * pe + lw;
-            t.active = e < n_edge;
-            if (e < 3 * si) {
-                const int which = e / si;                                 // 0: first chunk, 1 / 2: the last two
-                t.strip = 1 + (e - which * si);
-                t.r0 = which == 0 ? row_lo : (which == 1 ? row_last0 : row_last0 + Rl);
-                t.r1 = which == 0 ? row_lo + Re : (which == 1 ? row_last0 + Rl : row_hi);
-            } else {
-                const int k = e - 3 * si;
-                const int chunk = k >> 1;
-                t.strip = (k & 1) ? strips - 1 : 0;
-                t.r0 = row_lo + chunk * Re;
-                t.r1 = min(t.r0 + Re, row_hi);
-            }
-        } else {
-            const int m = xcd * pm + (lw - pe);
-            const int chunk = 1 + m / si;
-            t.active = (lw - pe) < pm && m < n_mid;
-            t.strip = 1 + (m - (chunk - 1) * si);
-            t.r0 = row_lo + Re + (chunk - 1) * R;
-            t.r1 = min(t.r0 + R, row_last0);
-        }
-        t.active = t.active && t.r0 < t.r1;
-        return t;
-    }
-    // uniform tiles: interior strips first (x fastest, a contiguous range per XCD, the upper four XCDs walking
-    // theirs backwards), then the two edge strips
-    const int b = xcd * per_xcd + (xcd >= 4 ? per_xcd - 1 - nth : nth);
-    const long g = (long)b * kWavesPerBlock + wave;
-    const long n_int = si > 0 ? (long)chunks * si : 0;
-    if (g < n_int) {
-        const int chunk = (int)(g / si);
-        t.strip = 1 + (int)(g - (long)chunk * si);
-        t.r0 = row_lo + chunk * R;
-        t.r1 = min(t.r0 + R, row_hi);
-        t.active = t.r0 < t.r1;
-    } else {
-        const long e = g - n_int;
-        int chunk;
-        if (si > 0) { chunk = (int)(e >> 1); t.strip = (e & 1) ? strips - 1 : 0; }
-        else { chunk = (int)(e / strips); t.strip = (int)(e - (long)chunk * strips); }
-        t.r0 = row_lo + chunk * Re;
-        t.r1 = min(t.r0 + Re, row_hi);
-        t.active = chunk < chunks_e && t.r0 < row_hi;
-    }
-    return t;
+    return cycle_tile_at((int)blockIdx.x, wave, (int)gridDim.x, strips, chunks, chunks_e, R, Re, row_lo, row_hi, row_last0, Rl,
+                         RB, n_tall, n_short);
 }
 
 struct Cols {           // per-lane column bookkeeping, shared by all kernels
@@ -1675,7 +1617,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
                T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,   // POST == 1
                double* __restrict__ partial,                          // POST == 2
                int N, long pitch, long cpitch, int row_lo, int row_hi, int R, int strips, int chunks, int Re, int chunks_e,
-               int row_last0, int Rl, T c0, T c1, int zero_in, CycleWin win)
+               int row_last0, int Rl, int RB, int n_tall, int n_short, T c0, T c1, int zero_in, CycleWin win)
 {
     constexpr int W = VecOf<T>::W;
     constexpr int XC = cycle_halo_cols<K, POST>();
@@ -1689,7 +1631,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     __shared__ typename LdsVec<T>::v bring[BL ? kWavesPerBlock * kBRing * kWave : 1];
     constexpr bool RAWQ = cycle_rawq<T, K, PRE, POST, SM, AR>();
     __shared__ typename LdsVec<T>::v braw[RAWQ ? kWavesPerBlock * kRawLds * kWave : 1];
-    const CTile t = cycle_tile(strips, chunks, chunks_e, R, Re, row_lo, row_hi, row_last0, Rl);
+    const CTile t = cycle_tile(strips, chunks, chunks_e, R, Re, row_lo, row_hi, row_last0, Rl, RB, n_tall, n_short);
     double acc = 0.0;
 #ifdef MGX_WAVE_TRACE
     const long long trace_t0 = wall_clock64();

@@ -82,17 +82,6 @@ void launch_rbgs(const T* vin, const T* b, T* vout, int N, long pitch, int row_l
 
 // chunk height >= R (in steps of `step`) for which a chunk's step count R + extra is a whole number of
 // loop trips, or one short of it when parity rules the exact fit out
-inline int trip_rows(int R, int extra, int trip, int step)
-{
-    int best = -1;
-    for (int r = R; r < R + 2 * trip; r += step) {
-        const int m = (r + extra) % trip;
-        if (m == 0) return r;
-        if (m == trip - 1 && best < 0) best = r;
-    }
-    return best < 0 ? R : best;
-}
-
 // K levels in one pass (k_jacobi_fused<T,K,SM>): K Jacobi sweeps (SM = 0) or K/2
 // red-black Gauss-Seidel sweeps (SM = 1)
 template <typename T, int K, int SM, int AR>
@@ -325,43 +314,25 @@ struct FoldArgs {
     CycleWin win{0, 0, 0, 0, 0, 0};
 };
 
-// chunk geometry of a k_jacobi_cycle launch (cycle_tile in mgx_kernels.hpp)
-struct CycleGeom { int R, Re, Rl, chunks, chunks_e, row_last0; long waves; };
-inline CycleGeom cycle_geom(int row_lo, int row_hi, int strips, int R, int Re, int Rl)
+// chunk geometry of a k_jacobi_cycle launch: mgx_geom.hpp (cycle_geom_pick / cycle_tile_at); the knobs from the environment
+inline const GeomKnobs& geom_knobs()
 {
-    const int rows = row_hi - row_lo;
-    CycleGeom g;
-    g.R = R; g.Re = Re; g.Rl = Rl;
-    g.chunks_e = (rows + Re - 1) / Re;
-    if (Re >= R || rows <= Re + 2 * Rl + 2 || strips < 3) {
-        // uniform tiles (of the edge height when the range is only a few edge tiles high)
-        g.R = (Re >= R) ? R : Re; g.Re = g.R; g.Rl = g.R;
-        g.row_last0 = 0;
-        g.chunks = g.chunks_e = (rows + g.R - 1) / g.R;
-    } else {
-        // first chunk Re rows; the last two Rl rows each at the end (the very last one row less when the
-        // parity of the range asks for it: every chunk starts on a row of row_lo's parity, and one row MORE
-        // could cost a whole loop trip)
-        const int last = row_hi - Rl + ((row_hi - Rl - row_lo) & 1);
-        g.row_last0 = last - Rl;
-        g.chunks = 3 + (g.row_last0 - (row_lo + Re) + R - 1) / R;
-    }
-    g.waves = strips > 2 ? (long)g.chunks * (strips - 2) + 2L * g.chunks_e : (long)g.chunks_e * strips;
-    return g;
+    static const GeomKnobs kn = [] {
+        GeomKnobs k;
+        k.edge_short = env_int("MGX_EDGE_SHORT", 1) != 0;
+        k.edge_pct = env_int("MGX_EDGE_PCT", 23);
+        k.last_pct = env_int("MGX_LAST_PCT", 38);
+        k.min_chunk = std::max(8, env_int("MGX_MIN_CHUNK", 16));
+        k.min_rounds = std::max(1, env_int("MGX_MIN_ROUNDS", 1));
+        k.min_rounds_rows = env_int("MGX_MIN_ROUNDS_ROWS", 1024);
+        k.pair = env_int("MGX_PAIR", 1) != 0;
+        k.pair_ratio = std::max(100, env_int("MGX_PAIR_RATIO", 130));
+        k.pair_max_rows = env_int("MGX_PAIR_MAX_ROWS", 640);
+        k.pair_min_rows = env_int("MGX_PAIR_MIN_ROWS", 200);
+        return k;
+    }();
+    return kn;
 }
-// height of the edge tiles for interior tiles R rows high: (Re + extra) / (R + extra) ~ 0.77, the inverse
-// of what an edge step costs relative to an interior one, in whole loop trips (MGX_EDGE_PCT: flat from 15
-// to 36 % at 8192^2, 4096^2 and 2048^2)
-inline int edge_rows(int R, int extra, int trip, int pct = -1)
-{
-    const double frac = 0.01 * (double)(pct >= 0 ? pct : env_int("MGX_EDGE_PCT", 23));
-    const int k = (int)(frac * (double)(R + extra) / (double)trip + 0.5);
-    const int Re = R - k * trip;
-    return Re >= trip ? Re : (R >= 2 * trip ? trip : R);
-}
-// the last two chunk rows (waves that reach the last row of the range: ~1.5 x an interior row step)
-inline int last_rows(int R, int extra, int trip) { return edge_rows(R, extra, trip, env_int("MGX_LAST_PCT", 38)); }
-
 // R < 0: choose the chunk height here (deep double passes: whole rounds of 2048 waves, see fuse_rows_deep;
 // -R is the height the uniform rule gave)
 template <typename T, int K, int PRE, int POST, int SM, int AR>
@@ -377,48 +348,18 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
     const CycleWin win = whole ? CycleWin{0, N, 0, N / 2, 1, N / 2} : fa.win;
     if (POST == 1 && !(row_lo & 1)) return -1;         // chunks must start on odd rows (POST = 1)
     const int strips = (N / VecOf<T>::W + OUT - 1) / OUT;
-    const bool edge_short = env_int("MGX_EDGE_SHORT", 1) != 0;
     const bool auto_rows = R < 0;
     if (auto_rows) R = -R;
-    if (R & 1) ++R;
-    // the bodies run whole trips (kBRing steps for the deep variants, kTrip otherwise): a chunk is
-    // R + 2K + (stage rows) steps long, so take the next even R that makes it a multiple of the trip (or
-    // one short of it)
-    R = trip_rows(R, 2 * K + E, kTripSteps, 2);
-    CycleGeom g = cycle_geom(row_lo, row_hi, strips, R, R, R);
-    if constexpr (BL) {
-        if (auto_rows) {
-            // the fewest rounds of 2048 waves with chunks of at most ~200 rows, and in that many rounds the
-            // shortest chunks that fit
-            bool found = false;
-            // MGX_MIN_ROUNDS (experiment knob, default 1): a launch of ONE round of workgroups (<= 512) is as fast per row
-            // step as one of several rounds (8192^2: one round of 348-row chunks 0.371-0.382 ms, two rounds of 168 0.374-0.377;
-            // the "25 % slower" recorded earlier for 328-row chunks was 520 workgroups, eight more than fit)
-            static const int min_chunk = std::max(8, env_int("MGX_MIN_CHUNK", 16));          // shortest chunk considered
-            static const int min_rounds = std::max(1, env_int("MGX_MIN_ROUNDS", 1));
-            static const int min_rounds_rows = env_int("MGX_MIN_ROUNDS_ROWS", 1024);    // ... for ranges at least this high
-            for (int m = (row_hi - row_lo >= min_rounds_rows ? min_rounds : 1); m <= 64 && !found; ++m) {
-                for (int r = trip_rows(min_chunk, 2 * K + E, kTripSteps, 2); r <= 204; r += kTripSteps) {
-                    const CycleGeom c = cycle_geom(row_lo, row_hi, strips, r, edge_short ? edge_rows(r, 2 * K + E, kTripSteps) : r,
-                                                   edge_short ? last_rows(r, 2 * K + E, kTripSteps) : r);
-                    if (c.waves <= 2048L * m) { g = c; found = true; break; }
-                }
-            }
-        } else if (edge_short) {
-            g = cycle_geom(row_lo, row_hi, strips, R, edge_rows(R, 2 * K + E, kTripSteps), last_rows(R, 2 * K + E, kTripSteps));
-        }
-    }
-    int blocks = (int)(((g.waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
-    if (g.row_last0 != 0) {
-        // two tile classes, an eighth of each per XCD (cycle_tile)
-        const int si = strips - 2;
-        const int pe = (3 * si + 2 * g.chunks_e + 7) / 8, pm = ((g.chunks - 3) * si + 7) / 8;
-        blocks = 8 * ((pe + pm + kWavesPerBlock - 1) / kWavesPerBlock);
-    }
+    // the bodies run whole trips (kBRing steps for the deep variants, kTrip otherwise): a chunk is R + 2K + (stage rows)
+    // steps long; cycle_geom_pick takes even heights that make it a multiple of the trip (or one short of it).
+    // Deep passes (rhs ring in LDS): shorter edge-class tiles; auto_rows: the fewest rounds of resident workgroups with
+    // chunks of at most ~200 rows, or ONE round with paired heights (mgx_geom.hpp)
+    const CycleGeom g = cycle_geom_pick(row_lo, row_hi, strips, 2 * K + E, kTripSteps, R, auto_rows, BL, geom_knobs());
+    const int blocks = g.blocks;
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
     hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM, AR>), dim3(blocks), dim3(kBlock), 0, st, vin, b, vout,
                        (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
-                       row_lo, row_hi, g.R, strips, g.chunks, g.Re, g.chunks_e, g.row_last0, g.Rl, c0, c1, fa.zero_in, win);
+                       row_lo, row_hi, g.R, strips, g.chunks, g.Re, g.chunks_e, g.row_last0, g.Rl, g.RB, g.n_tall, g.n_short, c0, c1, fa.zero_in, win);
     return blocks;
 }
 
