@@ -148,7 +148,13 @@ inline int fuse_rows_deep(int N, int rows)
 
 // deep double passes on big grids, height not given by MGX_FUSE_ROWS: launch_cycle_k sizes the chunks itself
 // (edge tiles shorter than interior ones) - it is handed -fuse_rows(...)
-inline bool fuse_rows_auto(const FuseCfg& fc, int N, int K, bool f64) { return fc.rows <= 0 && f64 && K >= 8 && N >= 2048; }
+// (float: the 10-level passes, whose rhs window is in LDS like the deep double ones - until round 3 they ran 32-row
+// chunks, 52 row steps for 32 rows)
+inline bool fuse_rows_auto(const FuseCfg& fc, int N, int K, bool f64)
+{
+    static const bool f32_auto = env_int("MGX_F32_AUTO_ROWS", 1) != 0;
+    return fc.rows <= 0 && (f64 ? K >= 8 : (K >= 10 && f32_auto)) && N >= 2048;
+}
 
 inline int fuse_rows(const FuseCfg& fc, int N, int K, bool f64 = true, int rows = 0)
 {

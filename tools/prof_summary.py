@@ -22,6 +22,21 @@ def short(name):
     return re.sub(r"\(.*$", "", name)
 
 
+def clusters(values, ratio=1.6):
+    """Two levels of one hierarchy can launch the same kernel with the same number of workgroups (8192^2 in one round of
+    paired chunks and 4096^2 in one uniform round are both 512): split a group whose sorted values jump by more than
+    `ratio` into sub-groups, largest first.  Returns a list of index lists."""
+    order = sorted(range(len(values)), key=lambda i: -values[i])
+    out, cur = [], [order[0]]
+    for a, b in zip(order, order[1:]):
+        if values[b] > 0 and values[a] / values[b] > ratio or (values[b] <= 0 < values[a]):
+            out.append(cur)
+            cur = []
+        cur.append(b)
+    out.append(cur)
+    return out
+
+
 def kt(path):
     groups = defaultdict(list)
     with open(path) as fh:
@@ -32,8 +47,14 @@ def kt(path):
     total = sum(sum(v) for v in groups.values())
     print("| kernel | workgroups | calls | avg us | min us | max us | total ms | % | VGPR | SGPR | LDS | scratch |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|")
-    for key, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
-        name, wgs, vg, sg, lds, scr = key
+    split = {}
+    for key, v in groups.items():
+        cl = clusters(v)
+        for n, idx in enumerate(cl):
+            split[key[:2] + ((f" ({'abcdefgh'[n]})" if len(cl) > 1 else ""),) + key[2:]] = [v[i] for i in idx]
+    for key, v in sorted(split.items(), key=lambda kv: -sum(kv[1])):
+        name, wgs, tag, vg, sg, lds, scr = key
+        wgs = f"{wgs}{tag}"
         print(f"| {name} | {wgs} | {len(v)} | {sum(v) / len(v) / 1e3:.2f} | {min(v) / 1e3:.2f} | {max(v) / 1e3:.2f} | "
               f"{sum(v) / 1e6:.3f} | {100.0 * sum(v) / total:.2f} | {vg} | {sg} | {lds} | {scr} |")
 
@@ -50,7 +71,15 @@ def pmc(paths):
     out = {}
     print("| kernel | workgroups | launches | counter | avg per launch |")
     print("|---|---|---|---|---|")
-    for key, ctrs in sorted(vals.items(), key=lambda kv: -max(sum(x) for x in kv[1].values())):
+    split = {}
+    for key, ctrs in vals.items():
+        # (sub-groups by the first counter's values: launches of one group come in the same order in every counter)
+        first = sorted(ctrs)[0]
+        cl = clusters(ctrs[first])
+        for n, idx in enumerate(cl):
+            tag = f" ({'abcdefgh'[n]})" if len(cl) > 1 else ""
+            split[(key[0], f"{key[1]}{tag}")] = {c: [v[i] for i in idx if i < len(v)] for c, v in ctrs.items()}
+    for key, ctrs in sorted(split.items(), key=lambda kv: -max(sum(x) for x in kv[1].values())):
         rec = {}
         for c, v in sorted(ctrs.items()):
             rec[c] = sum(v) / len(v)
