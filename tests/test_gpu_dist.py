@@ -293,17 +293,19 @@ def test_poisson_driver_binary_runs_the_reference_sequence(pkg):
     assert "fullmultigrid: " in out4.stdout                                   # PS:727 on the slabs too
 
 
-def test_config4_grid_on_eight_slabs_equals_the_single_gpu_solve(pkg):
+@pytest.mark.parametrize("P", [8, 4])
+def test_config4_grid_on_slabs_equals_the_single_gpu_solve(pkg, P):
     """BASELINE config 4's grid (16384^2, levels 14..7, the reference's V(10,10)) through the C++
     driver with the decomposition `bench.py --gpus 8` uses (levels 14..11 on slabs, <= 10 replicated),
-    all eight slabs on this one GPU: one cycle, bit for bit the single-GPU mgx_solve"""
+    all eight slabs on this one GPU: one cycle, bit for bit the single-GPU mgx_solve.  (P = 4: 4096-row
+    slabs, whose passes run in one round of paired chunk heights like the whole 8192^2 grid - csrc/mgx_geom.hpp)"""
     kw = dict(finest_level=14, coarsest_level=7, mu1=10, mu2=10, schedule=0)
     with pkg.Multigrid(**kw) as one:
         one.fill_rhs(1, 0.0)
         one.fill_guess_random(12345)
         s1, h1 = one.solve(tol=0.0, max_cycles=1)
         u1 = one.get_solution()
-    with pkg.Multigrid(n_gpus=8, devices=[0] * 8, **kw) as many:
+    with pkg.Multigrid(n_gpus=P, devices=[0] * P, **kw) as many:
         many.fill_rhs(1, 0.0)
         many.fill_guess_random(12345)
         s8, h8 = many.solve(tol=0.0, max_cycles=1)
