@@ -36,7 +36,8 @@ constexpr int kGeomCusPerXcd = 32;                 // MI355X: 256 CUs in 8 XCDs
 constexpr int kGeomResidentBlocks = 512;           // two workgroups of the deep passes per CU
 
 struct CycleGeom {
-    int R, Re, Rl;              // rows of a middle (tall) chunk, of an edge-class chunk, of each of the last two chunks
+    int R, Re, Rl;              // rows of a middle (tall) chunk, of a chunk of the two edge strips, of each of the last two chunks
+    int Rf;                     // rows of the first chunk of an interior strip (Re where the range starts at a boundary, else R)
     int chunks, chunks_e;       // chunks of an interior strip (first + middle + last two), of an edge strip
     int row_last0;              // first row of the last-but-one chunk; 0: uniform tiles of R = Re rows everywhere
     int RB, n_tall, n_short;    // paired form: rows of a short chunk, tall and short chunks per interior strip (n_tall = 0: uniform)
@@ -50,7 +51,7 @@ MGX_GEOM_HD int geom_min(int a, int b) { return a < b ? a : b; }
 
 // the tile of wave `wave` of block `block` in a grid of `grid` blocks (a multiple of 8)
 MGX_GEOM_HD CTile cycle_tile_at(int block, int wave, int grid, int strips, int chunks, int chunks_e, int R, int Re, int row_lo,
-                                int row_hi, int row_last0, int Rl, int RB, int n_tall, int n_short)
+                                int row_hi, int row_last0, int Rl, int RB, int n_tall, int n_short, int Rf)
 {
     const int per_xcd = grid >> 3;
     const int xcd = block & 7;
@@ -87,7 +88,7 @@ MGX_GEOM_HD CTile cycle_tile_at(int block, int wave, int grid, int strips, int c
                 const int which = e / si;                                 // 0: first chunk, 1 / 2: the last two
                 t.strip = 1 + (e - which * si);
                 t.r0 = which == 0 ? row_lo : (which == 1 ? row_last0 : row_last0 + Rl);
-                t.r1 = which == 0 ? row_lo + Re : (which == 1 ? row_last0 + Rl : row_hi);
+                t.r1 = which == 0 ? row_lo + Rf : (which == 1 ? row_last0 + Rl : row_hi);
             } else {
                 const int k = e - 3 * si;
                 const int chunk = k >> 1;
@@ -99,13 +100,13 @@ MGX_GEOM_HD CTile cycle_tile_at(int block, int wave, int grid, int strips, int c
             const int chunk = m / si;
             t.active = true;
             t.strip = 1 + (m - chunk * si);
-            t.r0 = row_lo + Re + chunk * R;
+            t.r0 = row_lo + Rf + chunk * R;
             t.r1 = geom_min(t.r0 + R, row_last0);
         } else if (s >= 0) {
             const int chunk = s / si;
             t.active = true;
             t.strip = 1 + (s - chunk * si);
-            t.r0 = row_lo + Re + n_tall * R + chunk * RB;
+            t.r0 = row_lo + Rf + n_tall * R + chunk * RB;
             t.r1 = geom_min(t.r0 + RB, row_last0);
         }
         t.active = t.active && t.r0 < t.r1;
@@ -189,25 +190,28 @@ inline int geom_blocks(const CycleGeom& g, int strips)
     return blocks;
 }
 
-// uniform middle chunks of R rows; edge-class chunks Re, the last two Rl
-inline CycleGeom cycle_geom(int row_lo, int row_hi, int strips, int R, int Re, int Rl)
+// uniform middle chunks of R rows; chunks of the two edge strips Re; first chunk of an interior strip Rf, its last two Rl
+// (callers pass Rf = Re and a shortened Rl where that end of the range is a boundary of the grid or of the rows that
+// exist - the waves there run the edge body - and Rf = R / Rl = R where it is not)
+inline CycleGeom cycle_geom(int row_lo, int row_hi, int strips, int R, int Re, int Rl, int Rf = -1)
 {
     const int rows = row_hi - row_lo;
+    if (Rf < 0) Rf = Re;
     CycleGeom g;
-    g.R = R; g.Re = Re; g.Rl = Rl; g.RB = 0; g.n_tall = 0; g.n_short = 0;
+    g.R = R; g.Re = Re; g.Rl = Rl; g.Rf = Rf; g.RB = 0; g.n_tall = 0; g.n_short = 0;
     g.chunks_e = (rows + Re - 1) / Re;
-    if (Re >= R || rows <= Re + 2 * Rl + 2 || strips < 3) {
+    if ((Re >= R && Rf >= R && Rl >= R) || rows <= Rf + 2 * Rl + 2 || strips < 3) {
         // uniform tiles (of the edge height when the range is only a few edge tiles high)
-        g.R = (Re >= R) ? R : Re; g.Re = g.R; g.Rl = g.R;
+        g.R = (Re >= R) ? R : Re; g.Re = g.R; g.Rl = g.R; g.Rf = g.R;
         g.row_last0 = 0;
         g.chunks = g.chunks_e = (rows + g.R - 1) / g.R;
     } else {
-        // first chunk Re rows; the last two Rl rows each at the end (the very last one row less when the
+        // first chunk Rf rows; the last two Rl rows each at the end (the very last one row less when the
         // parity of the range asks for it: every chunk starts on a row of row_lo's parity, and one row MORE
         // could cost a whole loop trip)
         const int last = row_hi - Rl + ((row_hi - Rl - row_lo) & 1);
         g.row_last0 = last - Rl;
-        g.chunks = 3 + (g.row_last0 - (row_lo + Re) + R - 1) / R;
+        g.chunks = 3 + (g.row_last0 - (row_lo + Rf) + R - 1) / R;
     }
     g.waves = strips > 2 ? (long)g.chunks * (strips - 2) + 2L * g.chunks_e : (long)g.chunks_e * strips;
     g.blocks = geom_blocks(g, strips);
@@ -215,7 +219,8 @@ inline CycleGeom cycle_geom(int row_lo, int row_hi, int strips, int R, int Re, i
 }
 
 // paired form for ONE round of workgroups; returns false when none fits (extra = row steps of a chunk beyond its rows)
-inline bool cycle_geom_paired(int row_lo, int row_hi, int strips, int extra, int trip, const GeomKnobs& kn, CycleGeom* out)
+inline bool cycle_geom_paired(int row_lo, int row_hi, int strips, int extra, int trip, const GeomKnobs& kn, bool top_edge, bool bot_edge,
+                              CycleGeom* out)
 {
     const int rows = row_hi - row_lo;
     const int si = strips - 2;
@@ -228,13 +233,14 @@ inline bool cycle_geom_paired(int row_lo, int row_hi, int strips, int extra, int
         const int ra = (steps_a - extra) & ~1;                        // even; ra + extra fills whole trips (or all but one step)
         if (ra > kn.pair_max_rows) break;
         if (ra <= rb) continue;
-        const int re = edge_rows_pct(ra, extra, trip, kn.edge_pct), rl = edge_rows_pct(ra, extra, trip, kn.last_pct);
-        if (rows <= re + 2 * rl + 2 + rb) continue;
+        const int re = edge_rows_pct(ra, extra, trip, kn.edge_pct), rl = bot_edge ? edge_rows_pct(ra, extra, trip, kn.last_pct) : ra;
+        const int rf = top_edge ? re : ra;
+        if (rows <= rf + 2 * rl + 2 + rb) continue;
         const int chunks_e = (rows + re - 1) / re;
         const int n_edge = 3 * si + 2 * chunks_e;
         const int last = row_hi - rl + ((row_hi - rl - row_lo) & 1);
         const int row_last0 = last - rl;
-        const int mid = row_last0 - (row_lo + re);                   // rows the tall and short chunks must cover
+        const int mid = row_last0 - (row_lo + rf);                   // rows the tall and short chunks must cover
         if (mid < rb) continue;
         // most tiles that fit: an eighth of each list per XCD, 128 waves per XCD and half
         const int nt_max = (8 * slots - 7 - n_edge) / si, ns_max = (8 * slots - 7) / si;   // (- 7: the per-XCD rounding)
@@ -252,7 +258,7 @@ inline bool cycle_geom_paired(int row_lo, int row_hi, int strips, int extra, int
         const int pf = (n_edge + nt * si + 7) / 8, ps = (ns * si + 7) / 8;
         if (pf > slots || ps > slots) continue;
         CycleGeom g;
-        g.R = ra; g.Re = re; g.Rl = rl; g.RB = rb; g.n_tall = nt; g.n_short = ns;
+        g.R = ra; g.Re = re; g.Rl = rl; g.Rf = rf; g.RB = rb; g.n_tall = nt; g.n_short = ns;
         g.chunks_e = chunks_e; g.row_last0 = row_last0; g.chunks = 3 + nt + ns;
         g.waves = (long)g.chunks * si + 2L * chunks_e;
         g.blocks = geom_blocks(g, strips);
@@ -267,7 +273,7 @@ inline bool cycle_geom_paired(int row_lo, int row_hi, int strips, int extra, int
 // auto_rows (deep double passes on big grids): the fewest rounds of resident workgroups with chunks of at most ~200
 // rows, and in that many rounds the shortest chunks that fit; one round: the paired form when it exists
 inline CycleGeom cycle_geom_pick(int row_lo, int row_hi, int strips, int extra, int trip, int R, bool auto_rows, bool deep,
-                                 const GeomKnobs& kn)
+                                 const GeomKnobs& kn, bool top_edge = true, bool bot_edge = true)
 {
     if (R & 1) ++R;
     R = trip_rows(R, extra, trip, 2);
@@ -275,13 +281,14 @@ inline CycleGeom cycle_geom_pick(int row_lo, int row_hi, int strips, int extra, 
     if (!deep) return g;
     auto shaped = [&](int r) {
         return cycle_geom(row_lo, row_hi, strips, r, kn.edge_short ? edge_rows_pct(r, extra, trip, kn.edge_pct) : r,
-                          kn.edge_short ? edge_rows_pct(r, extra, trip, kn.last_pct) : r);
+                          (kn.edge_short && bot_edge) ? edge_rows_pct(r, extra, trip, kn.last_pct) : r,
+                          (kn.edge_short && top_edge) ? edge_rows_pct(r, extra, trip, kn.edge_pct) : r);
     };
     if (!auto_rows) return kn.edge_short ? shaped(R) : g;
     if (kn.pair && kn.edge_short && strips >= 3) {
         // ONE round with paired chunk heights, when the range is small enough for it (pair_max_rows)
         CycleGeom p;
-        if (cycle_geom_paired(row_lo, row_hi, strips, extra, trip, kn, &p)) return p;
+        if (cycle_geom_paired(row_lo, row_hi, strips, extra, trip, kn, top_edge, bot_edge, &p)) return p;
     }
     bool found = false;
     for (int m = (row_hi - row_lo >= kn.min_rounds_rows ? kn.min_rounds : 1); m <= 64 && !found; ++m) {

@@ -288,13 +288,13 @@ __device__ int g_wave_trace_n;
 #endif
 // (the tile map itself is plain C++ shared with the launcher and the CPU tests: mgx_geom.hpp)
 __device__ __forceinline__ CTile cycle_tile(int strips, int chunks, int chunks_e, int R, int Re, int row_lo, int row_hi,
-                                            int row_last0, int Rl, int RB, int n_tall, int n_short)
+                                            int row_last0, int Rl, int RB, int n_tall, int n_short, int Rf)
 {
     // the wave index as a scalar: everything derived from it (chunk, rows, row offsets, the row predicates) then
     // lives in SGPRs and costs no vector instruction
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     return cycle_tile_at((int)blockIdx.x, wave, (int)gridDim.x, strips, chunks, chunks_e, R, Re, row_lo, row_hi, row_last0, Rl,
-                         RB, n_tall, n_short);
+                         RB, n_tall, n_short, Rf);
 }
 
 struct Cols {           // per-lane column bookkeeping, shared by all kernels
@@ -1125,22 +1125,14 @@ coarse_loads(PreFetch<T, VecOf<T>::W / 2>& pe, int y, const T* __restrict__ coar
     constexpr int CW = VecOf<T>::W / 2;
     const int I = y >> 1;
     if constexpr (!EDGE) {
-#if MGX_SOFF_LOADS
-        const unsigned srow = (unsigned)(I - fo.crb) * fo.cpitch_bytes;
+        // (coarse rows beyond the wave's cone: the nearest one that exists, as the fine rows in cycle_loads)
+        const int Ia = min(max(I, win.crow_first), win.crow_last), Ib = min(max(I + 1, win.crow_first), win.crow_last);
+        const unsigned srow_a = (unsigned)(Ia - fo.crb) * fo.cpitch_bytes, srow_b = (unsigned)(Ib - fo.crb) * fo.cpitch_bytes;
 #pragma unroll
-        for (int k = 0; k <= CW; ++k) pe.a[k] = bload1_s((T*)nullptr, fo.ce, fo.clane_off + (unsigned)(k * sizeof(T)), srow);
+        for (int k = 0; k <= CW; ++k) pe.a[k] = bload1_s((T*)nullptr, fo.ce, fo.clane_off + (unsigned)(k * sizeof(T)), srow_a);
         // the row below is only used by odd fine rows; loading it always keeps the step branch-free
 #pragma unroll
-        for (int k = 0; k <= CW; ++k) pe.b[k] = bload1_s((T*)nullptr, fo.ce, fo.clane_off + (unsigned)(k * sizeof(T)), srow + fo.cpitch_bytes);
-#else
-        const T* p = coarse_e + (long)I * cpitch + ccol;
-#pragma unroll
-        for (int k = 0; k <= CW; ++k) pe.a[k] = p[k];
-        // the row below is only used by odd fine rows; loading it always keeps the step branch-free
-        const T* q = p + cpitch;
-#pragma unroll
-        for (int k = 0; k <= CW; ++k) pe.b[k] = q[k];
-#endif
+        for (int k = 0; k <= CW; ++k) pe.b[k] = bload1_s((T*)nullptr, fo.ce, fo.clane_off + (unsigned)(k * sizeof(T)), srow_b);
     } else {
         const bool cl = cld && y > 0 && y < N && I >= win.crow_first && I + (y & 1) <= win.crow_last;
         const bool cl2 = cl && (y & 1);
@@ -1162,16 +1154,11 @@ cycle_loads(typename VecOf<T>::type& in, typename VecOf<T>::type& bn, int y,
     using V = typename VecOf<T>::type;
     if constexpr (!EDGE) {
         // interior body: no predicate, no branch (ZIN: the input is known to be all zero)
-#if MGX_SOFF_LOADS
-        const unsigned srow = (unsigned)(y - fo.rb) * fo.pitch_bytes;
+        // (rows beyond the wave's cone - see `interior` in k_jacobi_cycle - come from the nearest row that exists)
+        const int yi = min(y, win.row_last), yb = max(min(y - 1, win.row_last), win.row_first);
         if constexpr (ZIN) in = vzero((V*)nullptr);
-        else in = bload_s((V*)nullptr, fo.in, fo.lane_off, srow);
-        bn = bload_s((V*)nullptr, fo.rhs, fo.lane_off, srow - fo.pitch_bytes);
-#else
-        if constexpr (ZIN) in = vzero((V*)nullptr);
-        else in = *reinterpret_cast<const V*>(pv + (long)y * pitch);
-        bn = *reinterpret_cast<const V*>(pb + (long)(y - 1) * pitch);
-#endif
+        else in = bload_s((V*)nullptr, fo.in, fo.lane_off, (unsigned)(yi - fo.rb) * fo.pitch_bytes);
+        bn = bload_s((V*)nullptr, fo.rhs, fo.lane_off, (unsigned)(yb - fo.rb) * fo.pitch_bytes);
     } else {
         // edge body: no branch either - a row or lane that must not be read reads 0 through the
         // descriptor (win.row_first >= 0 and win.row_last <= N: the window also keeps y inside the grid)
@@ -1617,7 +1604,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
                T* __restrict__ coarse_b, T* __restrict__ coarse_zero, T wgt,   // POST == 1
                double* __restrict__ partial,                          // POST == 2
                int N, long pitch, long cpitch, int row_lo, int row_hi, int R, int strips, int chunks, int Re, int chunks_e,
-               int row_last0, int Rl, int RB, int n_tall, int n_short, T c0, T c1, int zero_in, CycleWin win)
+               int row_last0, int Rl, int RB, int n_tall, int n_short, int Rf, T c0, T c1, int zero_in, CycleWin win)
 {
     constexpr int W = VecOf<T>::W;
     constexpr int XC = cycle_halo_cols<K, POST>();
@@ -1631,7 +1618,7 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
     __shared__ typename LdsVec<T>::v bring[BL ? kWavesPerBlock * kBRing * kWave : 1];
     constexpr bool RAWQ = cycle_rawq<T, K, PRE, POST, SM, AR>();
     __shared__ typename LdsVec<T>::v braw[RAWQ ? kWavesPerBlock * kRawLds * kWave : 1];
-    const CTile t = cycle_tile(strips, chunks, chunks_e, R, Re, row_lo, row_hi, row_last0, Rl, RB, n_tall, n_short);
+    const CTile t = cycle_tile(strips, chunks, chunks_e, R, Re, row_lo, row_hi, row_last0, Rl, RB, n_tall, n_short, Rf);
     double acc = 0.0;
 #ifdef MGX_WAVE_TRACE
     const long long trace_t0 = wall_clock64();
@@ -1655,9 +1642,16 @@ k_jacobi_cycle(const T* __restrict__ vin, const T* __restrict__ rhs, T* __restri
         const int y_first = r0 - K - ETOP - 1;
         constexpr int SKD = cycle_skew<T, K, PRE, POST, SM, AR>() > 0 ? 1 : 0;            // the skewed chain's extra step
         const int y_lastp = (r0 - K - ETOP) + ((r1 + K + EBOT + SKD) - (r0 - K - ETOP) + kRound - 1) / kRound * kRound + kPrefetchMax;
+        // The unpredicated body is safe when the rows its STORED values depend on - input rows y0 = r0 - K - ETOP ..
+        // y_end - 1 = r1 + K + EBOT - 1 - are unknown rows that exist: the rows it touches beyond them (the rhs row of
+        // the first step, the rounding of the step count to whole trips, the prefetched rows) are loaded from the
+        // nearest row that exists (cycle_loads clamps the row number, two scalar instructions) and only feed values
+        // that are never stored.  The first and last chunks of a slab of a row-decomposed grid, whose halo rows are
+        // exactly the cone, therefore run the interior body too.
+        const int y0c = r0 - K - ETOP, y1c = r1 + K + EBOT - 1;
         bool interior = (vx0 >= 1) && ((long)(vx0 + kWave + 1) * W < N) &&
-                        (y_first > 0) && (y_lastp < N) && (y_first >= win.row_first) && (y_lastp <= win.row_last);
-        if (PRE) interior = interior && (y_first >> 1) >= win.crow_first && ((y_lastp >> 1) + 1) <= win.crow_last;
+                        (y0c > 0) && (y1c < N) && (y0c >= win.row_first) && (y1c <= win.row_last);
+        if (PRE) interior = interior && (y0c >> 1) >= win.crow_first && ((y1c + 1) >> 1) <= win.crow_last;
         interior = interior && !(PRE != 0 && zero_in);
         // both bodies store (and the edge body loads) through buffer descriptors that start at the first
         // row this wave can touch, with 32-bit offsets relative to it

@@ -360,12 +360,18 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
     // steps long; cycle_geom_pick takes even heights that make it a multiple of the trip (or one short of it).
     // Deep passes (rhs ring in LDS): shorter edge-class tiles; auto_rows: the fewest rounds of resident workgroups with
     // chunks of at most ~200 rows, or ONE round with paired heights (mgx_geom.hpp)
-    const CycleGeom g = cycle_geom_pick(row_lo, row_hi, strips, 2 * K + E, kTripSteps, R, auto_rows, BL, geom_knobs());
+    // an end of the range whose cone (K + 1 rows above, K + 1..2 below: the kernel's `interior`) leaves the unknown rows
+    // that exist runs the edge body and gets shorter chunks; the ends of a middle slab, whose halo rows hold the cone, do not
+    constexpr int ETOP = POST ? 1 : 0, EBOT = POST == 1 ? 2 : (POST == 2 ? 1 : 0);
+    static const bool ends_interior = env_int("MGX_SLAB_ENDS_INTERIOR", 1) != 0;      // 0: shortened chunks at every end of every range (the geometry before round 3's last change)
+    const bool top_edge = !ends_interior || (row_lo - K - ETOP) < std::max(win.row_first, 1) || (PRE && ((row_lo - K - ETOP) >> 1) < win.crow_first);
+    const bool bot_edge = !ends_interior || (row_hi + K + EBOT - 1) > std::min(win.row_last, N - 1) || (PRE && ((row_hi + K + EBOT) >> 1) > win.crow_last);
+    const CycleGeom g = cycle_geom_pick(row_lo, row_hi, strips, 2 * K + E, kTripSteps, R, auto_rows, BL, geom_knobs(), top_edge, bot_edge);
     const int blocks = g.blocks;
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
     hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM, AR>), dim3(blocks), dim3(kBlock), 0, st, vin, b, vout,
                        (const T*)fa.coarse_e, (T*)fa.coarse_b, (T*)fa.coarse_zero, w, fa.partial, N, pitch, fa.cpitch,
-                       row_lo, row_hi, g.R, strips, g.chunks, g.Re, g.chunks_e, g.row_last0, g.Rl, g.RB, g.n_tall, g.n_short, c0, c1, fa.zero_in, win);
+                       row_lo, row_hi, g.R, strips, g.chunks, g.Re, g.chunks_e, g.row_last0, g.Rl, g.RB, g.n_tall, g.n_short, g.Rf, c0, c1, fa.zero_in, win);
     return blocks;
 }
 

@@ -24,11 +24,13 @@ int main(int argc, char** argv)
         const int E = c.POST == 1 ? 3 : (c.POST == 2 ? 2 : 0);
         const int extra = 2 * c.K + E, trip = 12;
         if (c.POST == 1 && !(c.lo & 1)) continue;
-        const CycleGeom g = cycle_geom_pick(c.lo, c.hi, strips, extra, trip, 64, true, true, kn);
+        // (a slab's inner ends are not edges: its halo rows hold the cone)
+        const bool top_edge = c.lo == 1, bot_edge = c.hi == c.N;
+        const CycleGeom g = cycle_geom_pick(c.lo, c.hi, strips, extra, trip, 64, true, true, kn, top_edge, bot_edge);
         std::vector<int> cover((size_t)strips * (c.hi - c.lo), 0);
         long active = 0; int maxsteps = 0;
         for (int b = 0; b < g.blocks; ++b) for (int w = 0; w < 4; ++w) {
-            const CTile t = cycle_tile_at(b, w, g.blocks, strips, g.chunks, g.chunks_e, g.R, g.Re, c.lo, c.hi, g.row_last0, g.Rl, g.RB, g.n_tall, g.n_short);
+            const CTile t = cycle_tile_at(b, w, g.blocks, strips, g.chunks, g.chunks_e, g.R, g.Re, c.lo, c.hi, g.row_last0, g.Rl, g.RB, g.n_tall, g.n_short, g.Rf);
             if (!t.active) continue;
             ++active;
             if (t.strip < 0 || t.strip >= strips || t.r0 < c.lo || t.r1 > c.hi || ((t.r0 - c.lo) & 1)) { printf("BAD tile N=%d b=%d w=%d strip=%d r0=%d r1=%d\n", c.N, b, w, t.strip, t.r0, t.r1); ++fails; continue; }
@@ -38,8 +40,8 @@ int main(int argc, char** argv)
         long bad = 0; for (int v : cover) if (v != 1) ++bad;
         if (g.n_tall > 0 && g.blocks > kGeomResidentBlocks) { printf("PAIRED geometry of %d blocks N=%d rows %d..%d\n", g.blocks, c.N, c.lo, c.hi); ++fails; }
         if (bad || (g.blocks & 7)) { printf("COVERAGE FAIL N=%d rows %d..%d K=%d POST=%d: %ld cells, blocks %d\n", c.N, c.lo, c.hi, c.K, c.POST, bad, g.blocks); ++fails; }
-        if (argc > 1) printf("N=%5d rows %5d..%5d K=%2d POST=%d strips %3d: R %3d Re %3d Rl %3d RB %3d tall %2d short %2d chunks %2d/%2d blocks %4d (%.2f rounds) active %ld longest %d steps\n",
-               c.N, c.lo, c.hi, c.K, c.POST, strips, g.R, g.Re, g.Rl, g.RB, g.n_tall, g.n_short, g.chunks, g.chunks_e, g.blocks, g.blocks / 512.0, active, maxsteps);
+        if (argc > 1) printf("N=%5d rows %5d..%5d K=%2d POST=%d strips %3d: R %3d Re %3d Rf %3d Rl %3d RB %3d tall %2d short %2d chunks %2d/%2d blocks %4d (%.2f rounds) active %ld longest %d steps\n",
+               c.N, c.lo, c.hi, c.K, c.POST, strips, g.R, g.Re, g.Rf, g.Rl, g.RB, g.n_tall, g.n_short, g.chunks, g.chunks_e, g.blocks, g.blocks / 512.0, active, maxsteps);
     }
     printf("%s (%zu cases)\n", fails ? "FAILED" : "ok", cases.size());
     return fails != 0;
