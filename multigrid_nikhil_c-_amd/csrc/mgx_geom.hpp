@@ -170,7 +170,7 @@ struct GeomKnobs {
     int pair = 1;               // MGX_PAIR: paired chunk heights in one-round launches
     int pair_ratio = 130;       // MGX_PAIR_RATIO: row steps of a tall chunk, in percent of a short one's
     int pair_max_rows = 640;    // MGX_PAIR_MAX_ROWS: tallest chunk the paired form may use
-    int pair_min_rows = 200;    // MGX_PAIR_MIN_ROWS: ranges whose short chunks would be lower keep the uniform rule
+    int pair_min_rows = 150;    // MGX_PAIR_MIN_ROWS: ranges whose short chunks would be lower keep the uniform rule
 };
 
 inline int geom_blocks(const CycleGeom& g, int strips)

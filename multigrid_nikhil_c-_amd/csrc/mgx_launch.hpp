@@ -334,7 +334,7 @@ inline const GeomKnobs& geom_knobs()
         k.pair = env_int("MGX_PAIR", 1) != 0;
         k.pair_ratio = std::max(100, env_int("MGX_PAIR_RATIO", 130));
         k.pair_max_rows = env_int("MGX_PAIR_MAX_ROWS", 640);
-        k.pair_min_rows = env_int("MGX_PAIR_MIN_ROWS", 200);
+        k.pair_min_rows = env_int("MGX_PAIR_MIN_ROWS", 150);
         return k;
     }();
     return kn;
