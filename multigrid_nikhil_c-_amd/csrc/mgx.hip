@@ -1776,7 +1776,7 @@ int slab_cycle_t(const mgx_slab* f, T* u, const T* b, T* tmp, int row_lo, int ro
     // latency-bound there - R + 2K row steps one after the other, however few rows - and the register-tile kernel does
     // the whole block in one launch of independent tiles.  Same arithmetic in the same order: same bits.
     {
-        static const long tile_points = env_int("MGX_SLAB_TILE_POINTS", 1 << 20);
+        const long tile_points = env_int("MGX_SLAB_TILE_POINTS", 1 << 20);          // (read per call: the parity tests switch it)
         const int lo = std::max(std::max(row_lo, first), 1), hi = std::min(std::min(row_hi, last), f->rows - 1);
         if (fc.tile_max_n > 0 && per * mu <= fc.tile_k && hi > lo && (long)(hi - lo) * N <= tile_points) {
             FoldArgs ta = fa;

@@ -321,23 +321,21 @@ struct FoldArgs {
 };
 
 // chunk geometry of a k_jacobi_cycle launch: mgx_geom.hpp (cycle_geom_pick / cycle_tile_at); the knobs from the environment
-inline const GeomKnobs& geom_knobs()
+// (read at every launch of a deep pass: the parity tests switch them inside one process)
+inline GeomKnobs geom_knobs()
 {
-    static const GeomKnobs kn = [] {
-        GeomKnobs k;
-        k.edge_short = env_int("MGX_EDGE_SHORT", 1) != 0;
-        k.edge_pct = env_int("MGX_EDGE_PCT", 23);
-        k.last_pct = env_int("MGX_LAST_PCT", 38);
-        k.min_chunk = std::max(8, env_int("MGX_MIN_CHUNK", 16));
-        k.min_rounds = std::max(1, env_int("MGX_MIN_ROUNDS", 1));
-        k.min_rounds_rows = env_int("MGX_MIN_ROUNDS_ROWS", 1024);
-        k.pair = env_int("MGX_PAIR", 1) != 0;
-        k.pair_ratio = std::max(100, env_int("MGX_PAIR_RATIO", 130));
-        k.pair_max_rows = env_int("MGX_PAIR_MAX_ROWS", 640);
-        k.pair_min_rows = env_int("MGX_PAIR_MIN_ROWS", 150);
-        return k;
-    }();
-    return kn;
+    GeomKnobs k;
+    k.edge_short = env_int("MGX_EDGE_SHORT", 1) != 0;
+    k.edge_pct = env_int("MGX_EDGE_PCT", 23);
+    k.last_pct = env_int("MGX_LAST_PCT", 38);
+    k.min_chunk = std::max(8, env_int("MGX_MIN_CHUNK", 16));
+    k.min_rounds = std::max(1, env_int("MGX_MIN_ROUNDS", 1));
+    k.min_rounds_rows = env_int("MGX_MIN_ROUNDS_ROWS", 1024);
+    k.pair = env_int("MGX_PAIR", 1) != 0;
+    k.pair_ratio = std::max(100, env_int("MGX_PAIR_RATIO", 130));
+    k.pair_max_rows = env_int("MGX_PAIR_MAX_ROWS", 640);
+    k.pair_min_rows = env_int("MGX_PAIR_MIN_ROWS", 150);
+    return k;
 }
 // R < 0: choose the chunk height here (deep double passes: whole rounds of 2048 waves, see fuse_rows_deep;
 // -R is the height the uniform rule gave)
@@ -363,10 +361,10 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
     // an end of the range whose cone (K + 1 rows above, K + 1..2 below: the kernel's `interior`) leaves the unknown rows
     // that exist runs the edge body and gets shorter chunks; the ends of a middle slab, whose halo rows hold the cone, do not
     constexpr int ETOP = POST ? 1 : 0, EBOT = POST == 1 ? 2 : (POST == 2 ? 1 : 0);
-    static const bool ends_interior = env_int("MGX_SLAB_ENDS_INTERIOR", 1) != 0;      // 0: shortened chunks at every end of every range (the geometry before round 3's last change)
+    const bool ends_interior = env_int("MGX_SLAB_ENDS_INTERIOR", 1) != 0;      // 0: shortened chunks at every end of every range (the geometry before round 3's last change)
     const bool top_edge = !ends_interior || (row_lo - K - ETOP) < std::max(win.row_first, 1) || (PRE && ((row_lo - K - ETOP) >> 1) < win.crow_first);
     const bool bot_edge = !ends_interior || (row_hi + K + EBOT - 1) > std::min(win.row_last, N - 1) || (PRE && ((row_hi + K + EBOT) >> 1) > win.crow_last);
-    const CycleGeom g = cycle_geom_pick(row_lo, row_hi, strips, 2 * K + E, kTripSteps, R, auto_rows, BL, geom_knobs(), top_edge, bot_edge);
+    const CycleGeom g = cycle_geom_pick(row_lo, row_hi, strips, 2 * K + E, kTripSteps, R, auto_rows, BL, BL ? geom_knobs() : GeomKnobs(), top_edge, bot_edge);
     const int blocks = g.blocks;
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
     hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM, AR>), dim3(blocks), dim3(kBlock), 0, st, vin, b, vout,

@@ -135,14 +135,26 @@ def test_slab_argument_validation(pkg):
     hm.synchronize()
 
 
+# path: "tile" = the register-tile kernel (what a range this small gets), "march" = the marching passes
+# (MGX_SLAB_TILE_POINTS=0), "paired" = marching with the one-round paired chunk heights forced on (csrc/mgx_geom.hpp);
+# extra: halo rows beyond the sweeps - 3 is exactly the cone of the residual + restriction stage, so the interior body
+# runs on chunks whose loads beyond the cone are clamped to the rows that exist
+@pytest.mark.parametrize("path,extra", [("tile", 4), ("march", 4), ("march", 3), ("paired", 3)])
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 @pytest.mark.parametrize("smoother,mu", [("jacobi", 10), ("jacobi", 3), ("rbgs", 3)])
-def test_slab_cycle_equals_the_separate_slab_operators(pkg, po, dt, smoother, mu):
+def test_slab_cycle_equals_the_separate_slab_operators(pkg, po, dt, smoother, mu, path, extra, monkeypatch):
     """mgx_slab_cycle on an INTERIOR slab (halo rows on both sides, window narrower than the grid)
     against the oracle's whole-grid operators: correction on load, residual + restriction of
     the result, and the norm of the result - and its argument checks."""
+    for k in ("MGX_SLAB_TILE_POINTS", "MGX_PAIR_MIN_ROWS", "MGX_MIN_CHUNK"):
+        monkeypatch.delenv(k, raising=False)
+    if path != "tile":
+        monkeypatch.setenv("MGX_SLAB_TILE_POINTS", "0")
+    if path == "paired":
+        monkeypatch.setenv("MGX_PAIR_MIN_ROWS", "8")
+        monkeypatch.setenv("MGX_MIN_CHUNK", "8")
     L = pkg.lib()
-    level = 9
+    level = 11 if path == "paired" else 9          # (the launcher sizes chunks itself from 2048^2 up)
     N, NC = 1 << level, 1 << (level - 1)
     code = pkg.DTYPE_F64 if dt == np.float64 else pkg.DTYPE_F32
     kind = pkg.SMOOTHER_RBGS if smoother == "rbgs" else pkg.SMOOTHER_JACOBI
@@ -152,8 +164,8 @@ def test_slab_cycle_equals_the_separate_slab_operators(pkg, po, dt, smoother, mu
     f = rng.uniform(-1, 1, (N - 1, N - 1)).astype(dt)
     e = rng.uniform(-1, 1, (NC - 1, NC - 1)).astype(dt)
     sm = po.rbgs if smoother == "rbgs" else po.jacobi
-    own_lo, own_hi = 128, 256                      # owned fine rows [128, 256): an interior slab
-    halo = per * mu + 4
+    own_lo, own_hi = N // 4, N // 2                # owned fine rows [128, 256) of 512: an interior slab
+    halo = per * mu + extra
     lo, hi = own_lo - halo, own_hi + halo
     clo, chi = lo // 2 - 1, hi // 2 + 2            # coarse rows the slab holds
     U, B = grid_from_interior(pkg, v, level, dt), grid_from_interior(pkg, f, level, dt)

@@ -467,12 +467,19 @@ def test_chunk_geometry_knobs_of_the_deep_passes_never_change_a_bit(pkg, po, mon
     cfg = dict(finest_level=11, coarsest_level=8, mu1=10, mu2=10, schedule=0)
     b = po.rhs_sine(11)
     u0 = po.fill_uniform(b.shape, 99)
-    keys = ("MGX_EDGE_SHORT", "MGX_EDGE_PCT", "MGX_LAST_PCT", "MGX_FUSE_ROWS", "MGX_TILE_MAX_N")
+    keys = ("MGX_EDGE_SHORT", "MGX_EDGE_PCT", "MGX_LAST_PCT", "MGX_FUSE_ROWS", "MGX_TILE_MAX_N", "MGX_PAIR", "MGX_PAIR_MIN_ROWS",
+            "MGX_PAIR_RATIO", "MGX_PAIR_MAX_ROWS", "MGX_MIN_CHUNK")
     ref = None
+    # (MGX_PAIR_MIN_ROWS=16: the one-round form with tall chunks on the workgroups dispatched first and short ones on the
+    # rest - csrc/mgx_geom.hpp - which the launcher keeps for chunks of 150 rows and more, on these small levels too)
     for env in ({}, {"MGX_EDGE_SHORT": "0"}, {"MGX_EDGE_PCT": "40"}, {"MGX_EDGE_PCT": "8"}, {"MGX_FUSE_ROWS": "36"},
                 {"MGX_FUSE_ROWS": "60", "MGX_EDGE_SHORT": "0"}, {"MGX_FUSE_ROWS": "300"}, {"MGX_FUSE_ROWS": "2046"},
                 {"MGX_FUSE_ROWS": "1020", "MGX_EDGE_PCT": "45"}, {"MGX_LAST_PCT": "5"}, {"MGX_LAST_PCT": "70", "MGX_EDGE_PCT": "0"},
-                {"MGX_FUSE_ROWS": "96", "MGX_LAST_PCT": "50"}):
+                {"MGX_FUSE_ROWS": "96", "MGX_LAST_PCT": "50"},
+                {"MGX_PAIR_MIN_ROWS": "16"}, {"MGX_PAIR_MIN_ROWS": "16", "MGX_PAIR_RATIO": "200"},
+                {"MGX_PAIR_MIN_ROWS": "16", "MGX_PAIR_RATIO": "110", "MGX_EDGE_PCT": "0"},
+                {"MGX_PAIR_MIN_ROWS": "16", "MGX_PAIR_RATIO": "170", "MGX_LAST_PCT": "60", "MGX_MIN_CHUNK": "40"},
+                {"MGX_PAIR_MIN_ROWS": "16", "MGX_PAIR_MAX_ROWS": "100"}, {"MGX_PAIR": "0"}):
         for k in keys:
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("MGX_TILE_MAX_N", "0")
