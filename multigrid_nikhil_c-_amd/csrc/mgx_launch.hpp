@@ -364,7 +364,11 @@ int launch_cycle_k(const T* vin, const T* b, T* vout, const FoldArgs& fa, int N,
     const bool ends_interior = env_int("MGX_SLAB_ENDS_INTERIOR", 1) != 0;      // 0: shortened chunks at every end of every range (the geometry before round 3's last change)
     const bool top_edge = !ends_interior || (row_lo - K - ETOP) < std::max(win.row_first, 1) || (PRE && ((row_lo - K - ETOP) >> 1) < win.crow_first);
     const bool bot_edge = !ends_interior || (row_hi + K + EBOT - 1) > std::min(win.row_last, N - 1) || (PRE && ((row_hi + K + EBOT) >> 1) > win.crow_last);
-    const CycleGeom g = cycle_geom_pick(row_lo, row_hi, strips, 2 * K + E, kTripSteps, R, auto_rows, BL, BL ? geom_knobs() : GeomKnobs(), top_edge, bot_edge);
+    GeomKnobs kn = BL ? geom_knobs() : GeomKnobs();
+    // (float passes: a wave covers twice the columns, a grid has half the strips and twice the chunks per strip - the paired
+    // form pays from shorter chunks: mixed V(10,10) at 8192^2, float finest-level passes 0.403 -> 0.393-0.395 ms at 100 rows)
+    if (sizeof(T) == 4 && BL) kn.pair_min_rows = std::min(kn.pair_min_rows, env_int("MGX_PAIR_MIN_ROWS_F32", 100));
+    const CycleGeom g = cycle_geom_pick(row_lo, row_hi, strips, 2 * K + E, kTripSteps, R, auto_rows, BL, kn, top_edge, bot_edge);
     const int blocks = g.blocks;
     const T w = (fa.restrict_mode == MGX_RESTRICT_FW16) ? (T)0.0625 : (T)0.25;
     hipLaunchKernelGGL((k_jacobi_cycle<T, K, PRE, POST, SM, AR>), dim3(blocks), dim3(kBlock), 0, st, vin, b, vout,
