@@ -159,8 +159,17 @@ inline bool fuse_rows_auto(const FuseCfg& fc, int N, int K, bool f64)
 inline int fuse_rows(const FuseCfg& fc, int N, int K, bool f64 = true, int rows = 0)
 {
     if (fc.rows > 0) return fc.rows;
-    if (K <= 2) return 8;
-    if (K <= 4) return N >= 8192 ? 24 : 16;
+    if (K <= 2) {
+        // (8192^2 and up: 96 rows like the K <= 4 passes below - together −2..−3.5 % on the finest-level part of a V(2,1) cycle)
+        static const int big2 = env_int("MGX_SHALLOW2_ROWS_BIG", 96);
+        return N >= 8192 ? big2 : 8;
+    }
+    if (K <= 4) {
+        // (8192^2 and up: 96 rows - finest-level part of the red-black V(2,1) cycle 0.828-0.833 -> 0.789 ms, Jacobi V(2,1)
+        // 0.811-0.817 -> 0.786-0.794; round 1's 24 rows paid (24 + 2K) / 24 in recomputed rows)
+        static const int big = env_int("MGX_SHALLOW_ROWS_BIG", 96);
+        return N >= 8192 ? big : 16;
+    }
     if (f64 && K >= 8 && N >= 2048) return fuse_rows_deep(N, rows > 0 ? rows : N - 1);
     int R = N / 128;
     if (R < 8) R = 8;
