@@ -541,6 +541,13 @@ bool smooth_folded(mgx_solver* s, int level, int mu, bool pre, int post, bool ze
     const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
     bool ok;
     const bool fma = s->fuse.arith != 0;
+    // float: the 10-level pass with BOTH the correction stage and the norm stage does not fit its registers (mgx_launch.hpp,
+    // cycle_k_supported) and a block of 10 would run as two passes of 5 (8192^2: 223 + 190 us); one 10-level pass without
+    // the norm stage and the stand-alone norm kernel are 216 + ~110 us
+    static const bool f32_norm_apart = env_int("MGX_F32_NORM_APART", 1) != 0;
+    if (!l.f64 && pre && post == 2 && !rbgs && mu == 10 && l.N > s->fuse.tile_max_n && f32_norm_apart &&
+        cycle_k_supported(mu, false, false, 0, true, s->fuse.arith) && !cycle_k_supported(mu, false, false, 2, true, s->fuse.arith))
+        post = 0;
     if (l.f64) ok = rbgs ? smooth_folded_t<double, 1, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
                          : (fma ? smooth_folded_t<double, 0, 1>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
                                 : smooth_folded_t<double, 0, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in));
