@@ -156,19 +156,23 @@ inline bool fuse_rows_auto(const FuseCfg& fc, int N, int K, bool f64)
     return fc.rows <= 0 && (f64 ? K >= 8 : (K >= 10 && f32_auto)) && N >= 2048;
 }
 
+inline int shallow_big_n() { static const int n = env_int("MGX_SHALLOW_BIG_N", 8192); return n; }
+// (4096^2: 48 rows - config 2's V(2,1) cycle 0.416-0.418 -> 0.389-0.395 ms, the 4096^2 level of config 3 -4 %; 96 there: 0.402)
+inline int shallow_mid_rows() { static const int r = env_int("MGX_SHALLOW_ROWS_MID", 48); return r; }
+
 inline int fuse_rows(const FuseCfg& fc, int N, int K, bool f64 = true, int rows = 0)
 {
     if (fc.rows > 0) return fc.rows;
     if (K <= 2) {
         // (8192^2 and up: 96 rows like the K <= 4 passes below - together −2..−3.5 % on the finest-level part of a V(2,1) cycle)
         static const int big2 = env_int("MGX_SHALLOW2_ROWS_BIG", 96);
-        return N >= 8192 ? big2 : 8;
+        return N >= shallow_big_n() ? big2 : (N >= 4096 ? shallow_mid_rows() : 8);
     }
     if (K <= 4) {
         // (8192^2 and up: 96 rows - finest-level part of the red-black V(2,1) cycle 0.828-0.833 -> 0.789 ms, Jacobi V(2,1)
         // 0.811-0.817 -> 0.786-0.794; round 1's 24 rows paid (24 + 2K) / 24 in recomputed rows)
         static const int big = env_int("MGX_SHALLOW_ROWS_BIG", 96);
-        return N >= 8192 ? big : 16;
+        return N >= shallow_big_n() ? big : (N >= 4096 ? shallow_mid_rows() : 16);
     }
     if (f64 && K >= 8 && N >= 2048) return fuse_rows_deep(N, rows > 0 ? rows : N - 1);
     int R = N / 128;
