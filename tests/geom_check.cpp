@@ -14,6 +14,9 @@ int main(int argc, char** argv)
     std::vector<Case> cases;
     for (int L = 8; L <= 14; ++L) for (int post = 0; post < 3; ++post) { int N = 1 << L; cases.push_back({N, 1, N, 10, post, 2}); cases.push_back({N, 1, N, 8, post, 2}); }
     for (int P : {2, 4, 8}) for (int L = 11; L <= 14; ++L) for (int post = 0; post < 3; ++post) { int N = 1 << L; int rows = N / P; for (int r = 0; r < P; ++r) { int lo = r * rows + 1, hi = (r + 1) * rows + (r == P - 1 ? 0 : 1); if (r == P - 1) hi = N; cases.push_back({N, lo, std::min(hi, N), 10, post, 2}); } }
+    // float passes: four columns per lane, half the strips (the launcher lowers the paired form's threshold to 100 rows there)
+    for (int L = 11; L <= 14; ++L) for (int post = 0; post < 3; ++post) { int N = 1 << L; cases.push_back({N, 1, N, 10, post, 4}); }
+    for (int P : {2, 8}) for (int L = 12; L <= 14; ++L) { int N = 1 << L; int rows = N / P; for (int r = 0; r < P; ++r) cases.push_back({N, r * rows + 1, r == P - 1 ? N : (r + 1) * rows + 1, 10, 1, 4}); }
     GeomKnobs kn;
     if (getenv("PAIR")) kn.pair = atoi(getenv("PAIR"));
     if (getenv("RATIO")) kn.pair_ratio = atoi(getenv("RATIO"));
@@ -26,7 +29,9 @@ int main(int argc, char** argv)
         if (c.POST == 1 && !(c.lo & 1)) continue;
         // (a slab's inner ends are not edges: its halo rows hold the cone)
         const bool top_edge = c.lo == 1, bot_edge = c.hi == c.N;
-        const CycleGeom g = cycle_geom_pick(c.lo, c.hi, strips, extra, trip, 64, true, true, kn, top_edge, bot_edge);
+        GeomKnobs kc = kn;
+        if (c.W == 4 && kc.pair_min_rows > 100) kc.pair_min_rows = 100;
+        const CycleGeom g = cycle_geom_pick(c.lo, c.hi, strips, extra, trip, 64, true, true, kc, top_edge, bot_edge);
         std::vector<int> cover((size_t)strips * (c.hi - c.lo), 0);
         long active = 0; int maxsteps = 0;
         for (int b = 0; b < g.blocks; ++b) for (int w = 0; w < 4; ++w) {
