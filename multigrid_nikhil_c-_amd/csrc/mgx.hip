@@ -536,27 +536,32 @@ bool smooth_folded(mgx_solver* s, int level, int mu, bool pre, int post, bool ze
     if (!fold_eligible(s, l, mu, pre, post)) return false;
     const Level* coarse = (pre || post == 1) ? &s->lv[level - 1] : nullptr;
     const bool fine = (level == s->cfg.finest_level);
-    Prof p(s, fine ? MGX_PROF_SMOOTH_FINE : MGX_PROF_COARSE, mu);
-    int launches = 0, nb = 0;
     const bool rbgs = (s->cfg.smoother == MGX_SMOOTHER_RBGS);
-    bool ok;
     const bool fma = s->fuse.arith != 0;
     // float: the 10-level pass with BOTH the correction stage and the norm stage does not fit its registers (mgx_launch.hpp,
     // cycle_k_supported) and a block of 10 would run as two passes of 5 (8192^2: 223 + 190 us); one 10-level pass without
-    // the norm stage and the stand-alone norm kernel are 216 + ~110 us
+    // the norm stage and the stand-alone norm kernel are 216 + ~110 us.  (The same for the restriction stage of the
+    // separately rounded mode - 10 levels + the stand-alone residual / restriction instead of 8 + 2 - was measured and is
+    // worse: mixed cycle 1.54 -> 1.72 ms, the stand-alone transfer alone is 0.15 ms.)
     static const bool f32_norm_apart = env_int("MGX_F32_NORM_APART", 1) != 0;
-    if (!l.f64 && pre && post == 2 && !rbgs && mu == 10 && l.N > s->fuse.tile_max_n && f32_norm_apart &&
-        cycle_k_supported(mu, false, false, 0, true, s->fuse.arith) && !cycle_k_supported(mu, false, false, 2, true, s->fuse.arith))
+    if (!l.f64 && !rbgs && mu == 10 && l.N > s->fuse.tile_max_n && f32_norm_apart && post == 2 && pre &&
+        cycle_k_supported(mu, false, false, 0, pre, s->fuse.arith) && !cycle_k_supported(mu, false, false, post, pre, s->fuse.arith))
         post = 0;
-    if (l.f64) ok = rbgs ? smooth_folded_t<double, 1, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
-                         : (fma ? smooth_folded_t<double, 0, 1>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
-                                : smooth_folded_t<double, 0, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in));
-    else ok = rbgs ? smooth_folded_t<float, 1, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
-                   : (fma ? smooth_folded_t<float, 0, 1>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
-                          : smooth_folded_t<float, 0, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in));
-    if (!ok) return false;
-    p.set(launches, mu);
-    if (post == 2) s->norm_blocks_ready = nb;
+    {
+        Prof p(s, fine ? MGX_PROF_SMOOTH_FINE : MGX_PROF_COARSE, mu);
+        int launches = 0, nb = 0;
+        bool ok;
+        if (l.f64) ok = rbgs ? smooth_folded_t<double, 1, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
+                             : (fma ? smooth_folded_t<double, 0, 1>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
+                                    : smooth_folded_t<double, 0, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in));
+        else ok = rbgs ? smooth_folded_t<float, 1, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
+                       : (fma ? smooth_folded_t<float, 0, 1>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in)
+                              : smooth_folded_t<float, 0, 0>(s, l, mu, coarse, pre, post, &launches, &nb, zero_in));
+        if (!ok) return false;
+        p.set(launches, mu);
+        if (post == 2) s->norm_blocks_ready = nb;
+    }
+    // (the norm stage left out: mgx_solve's residual_norm_grid finds norm_blocks_ready == 0 and runs the norm kernel)
     if (fine) s->fine_updates += (double)mu * (double)(l.N - 1) * (double)(l.N - 1);
     return true;
 }
