@@ -17,7 +17,24 @@ int main(int argc, char** argv)
     // float passes: four columns per lane, half the strips (the launcher lowers the paired form's threshold to 100 rows there)
     for (int L = 11; L <= 14; ++L) for (int post = 0; post < 3; ++post) { int N = 1 << L; cases.push_back({N, 1, N, 10, post, 4}); }
     for (int P : {2, 8}) for (int L = 12; L <= 14; ++L) { int N = 1 << L; int rows = N / P; for (int r = 0; r < P; ++r) cases.push_back({N, r * rows + 1, r == P - 1 ? N : (r + 1) * rows + 1, 10, 1, 4}); }
+    // FUZZ=<n>: n more cases with random levels, row ranges (odd first row), depths and stages
+    if (getenv("FUZZ")) {
+        unsigned long long st = 88172645463325252ull;
+        auto rnd = [&](int n) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (int)(st % (unsigned long long)n); };
+        for (int i = 0; i < atoi(getenv("FUZZ")); ++i) {
+            const int L = 11 + rnd(4), N = 1 << L;
+            int lo = 1 + 2 * rnd(N / 2 - 40), hi = lo + 24 + rnd(N - lo - 24);
+            if (hi > N) hi = N;
+            if (rnd(4) == 0) { lo = 1; }
+            if (rnd(4) == 0) { hi = N; }
+            cases.push_back({N, lo, hi, rnd(2) ? 10 : 8, rnd(3), rnd(3) ? 2 : 4});
+        }
+    }
     GeomKnobs kn;
+    if (getenv("MINCHUNK")) kn.min_chunk = atoi(getenv("MINCHUNK"));
+    if (getenv("PAIRMIN")) kn.pair_min_rows = atoi(getenv("PAIRMIN"));
+    if (getenv("EDGEPCT")) kn.edge_pct = atoi(getenv("EDGEPCT"));
+    if (getenv("LASTPCT")) kn.last_pct = atoi(getenv("LASTPCT"));
     if (getenv("PAIR")) kn.pair = atoi(getenv("PAIR"));
     if (getenv("RATIO")) kn.pair_ratio = atoi(getenv("RATIO"));
     for (const Case& c : cases) {
@@ -28,9 +45,10 @@ int main(int argc, char** argv)
         const int extra = 2 * c.K + E, trip = 12;
         if (c.POST == 1 && !(c.lo & 1)) continue;
         // (a slab's inner ends are not edges: its halo rows hold the cone)
-        const bool top_edge = c.lo == 1, bot_edge = c.hi == c.N;
+        const bool top_edge = c.lo - c.K - 2 < 1, bot_edge = c.hi + c.K + 2 > c.N - 1;
         GeomKnobs kc = kn;
         if (c.W == 4 && kc.pair_min_rows > 100) kc.pair_min_rows = 100;
+        if (c.K == 8 && c.W == 4) continue;               // (no deep 8-level float pass: its window is in registers)
         const CycleGeom g = cycle_geom_pick(c.lo, c.hi, strips, extra, trip, 64, true, true, kc, top_edge, bot_edge);
         std::vector<int> cover((size_t)strips * (c.hi - c.lo), 0);
         long active = 0; int maxsteps = 0;

@@ -16,7 +16,8 @@ def geom_check(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("env", [{}, {"PAIR": "0"}, {"RATIO": "125"}, {"RATIO": "200"}])
+@pytest.mark.parametrize("env", [{}, {"PAIR": "0"}, {"RATIO": "125"}, {"RATIO": "200"}, {"FUZZ": "3000"}, {"FUZZ": "3000", "PAIRMIN": "16", "MINCHUNK": "8"},
+                                 {"FUZZ": "2000", "PAIRMIN": "24", "RATIO": "170", "EDGEPCT": "0", "LASTPCT": "60"}, {"FUZZ": "2000", "PAIRMIN": "40", "EDGEPCT": "45", "LASTPCT": "5"}])
 def test_every_row_of_every_strip_is_covered_exactly_once(geom_check, env):
     r = subprocess.run([geom_check], env={**os.environ, **env}, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
