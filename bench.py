@@ -287,6 +287,26 @@ def run_single(args):
         },
     }
     mg.close()
+    # ---- the same K steps the way mgx_solve runs them when nobody is timing phases (cfg.profile = 0: the whole cycle and its
+    # norm replayed from ONE hipGraph, no events, no eager launches).  Informational: `value` above stays the number of the
+    # instrumented region the roofline figures come from.
+    try:
+        with pkg.Multigrid(**dict(cfg, profile=0)) as mg0:
+            mg0.fill_rhs(1, 0.0)
+            mg0.fill_guess_random(12345)
+            mg0.solve(tol=0.0, max_cycles=max(args.warmup, 2))
+            mg0.synchronize()
+            t0 = time.perf_counter()
+            st_off, _ = mg0.solve(tol=0.0, max_cycles=args.steps)
+            mg0.synchronize()
+            s_off = time.perf_counter() - t0
+        out["profiling_off"] = {
+            "ms_per_step": s_off / args.steps * 1e3, "value": st_off.fine_updates / s_off, "unit": "updates/s",
+            "how": f"{args.steps} more steps on a second handle with cfg.profile = 0 (one hipGraph replay per cycle + norm; the wall time "
+                   "includes the one initial residual norm of the mgx_solve call)",
+        }
+    except Exception as e:
+        out["profiling_off"] = {"error": str(e)}
     # ---- the HBM-bound regime, live: the same smoother with temporal fusion off
     # (one k_jacobi_rows / k_rbgs launch per sweep moves exactly its algorithmic
     # bytes), timed with HIP events on the solver's stream.  The fused passes
