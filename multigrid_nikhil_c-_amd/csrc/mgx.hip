@@ -126,7 +126,11 @@ struct Prof {
         if (!s->cfg.profile || s->prof_mute || mute_all) return;
         EventPair p;
         if (!s->ev_free.empty()) { p = s->ev_free.back(); s->ev_free.pop_back(); }
-        else { if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; }
+        else {
+            // timing only: no system-scope fence when the event completes (MGX_PROF_EVENT_FLAGS=0: plain events)
+            static const unsigned flags = env_int("MGX_PROF_EVENT_FLAGS", 1) ? hipEventDisableSystemFence : hipEventDefault;
+            if (hipEventCreateWithFlags(&p.a, flags) != hipSuccess || hipEventCreateWithFlags(&p.b, flags) != hipSuccess) return;
+        }
         p.cls = cls; p.launches = launches; p.sweeps = 0;
         p.a_use = p.a;
         if (s->prof_chain && s->chain_ev) p.a_use = s->chain_ev;
