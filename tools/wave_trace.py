@@ -114,3 +114,11 @@ if two:
           f"of the slower: p5 {np.percentile(blk[sl], 5):.0f} median {np.median(blk[sl]):.0f} p95 {np.percentile(blk[sl], 95):.0f}")
     hwslot = hw & 15
     print(f"  hardware wave slot of the faster: {np.bincount(hwslot[fa], minlength=10)[:10]}, of the slower: {np.bincount(hwslot[sl], minlength=10)[:10]}")
+# ---- by chunk height (the paired geometry of csrc/mgx_geom.hpp: tall chunks on the workgroups dispatched first, short ones on
+# the rest, edge-class chunks in between): when does each class end?
+print("  by chunk height (rows: waves, median start / end us, us per row step, share on hardware wave slot 0):")
+hs, cnt = np.unique(rows, return_counts=True)
+for h in hs[np.argsort(-cnt)][:6]:
+    m = rows == h
+    print(f"    {int(h):4d} rows: {int(m.sum()):5d} waves, start {np.median(start[m]):6.1f}, end {np.median(end[m]):6.1f} (p10 {np.percentile(end[m], 10):6.1f}, p90 {np.percentile(end[m], 90):6.1f}),"
+          f" {np.median(dur[m] / (rows[m] + 23)):.3f} us/step, slot 0: {np.mean((hw[m] & 15) == 0):.2f}")
